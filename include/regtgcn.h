@@ -1,0 +1,175 @@
+/* regtgcn.h -- C ABI of libregtgcn_hip.so, the MI355X (gfx950) implementation of the RegT-GCN
+ * forward/backward hot path.
+ *
+ * The reference (raynbowy23/RegT-GCN) is pure Python: its hot path has no FFI of its own, it
+ * reaches the device through torch / torch_geometric operator calls.  The entry points below are
+ * therefore the op sites of that path, one C function per site, so that a reference maintainer can
+ * bind them with ctypes (INTEGRATION.md shows the stub).  Citations are relative to the reference
+ * root.  All pointers are DEVICE pointers unless the name ends in `_host`; all matrices are
+ * row-major fp32; indices are int64 on input (the reference's edge_index dtype) and int32 inside
+ * prepared operators.  Every function enqueues on `stream` (a hipStream_t passed as void*), never
+ * synchronises, allocates nothing, and returns 0 on success or a non-zero code with a message
+ * available from regt_last_error().  Buffers are owned by the caller for the duration of the
+ * enqueued work.
+ */
+#ifndef REGTGCN_H
+#define REGTGCN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* regt_stream_t;
+
+#define REGT_ABI_VERSION 1
+
+int32_t regt_abi_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* regt_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph preparation (once per static graph).
+ *
+ * Replaces the normalisation PyG recomputes inside every conv call because the reference builds
+ * its layers with cached=False (models/RegionalTemporalGCN.py:54,73):
+ *   GCNConv  gcn_norm          -- call sites models/utils.py:169,175,181
+ *   ChebConv __norm__/get_laplacian -- call sites models/RegionalTemporalGCN.py:136-140,
+ *                                      models/TemporalGCN.py:88
+ * edge_index is the reference's (2,E) int64 tensor (row 0 = source, row 1 = target), edge_weight
+ * its (E,) fp32 edge_attr or NULL for unit weights.
+ * flags_dev[0] receives bit0 = an index was out of [0,N), bit1 = a negative weight was seen.
+ * ---------------------------------------------------------------------------------------------- */
+size_t regt_graph_workspace_bytes(int64_t num_edges, int32_t num_nodes);
+
+/* A_hat = D^-1/2 (A + I) D^-1/2 as a destination-sorted CSR; rowptr (N+1), col/val (E + N). */
+int32_t regt_gcn_csr(const int64_t* edge_index, const float* edge_weight, int64_t num_edges, int32_t num_nodes,
+                     int32_t* rowptr, int32_t* col, float* val, int32_t* flags_dev,
+                     void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* Per-edge scaled-Laplacian weights of ChebConv(K=2, 'sym', lambda_max=None): out_weight (E). */
+int32_t regt_cheb_edge_weights(const int64_t* edge_index, const float* edge_weight, int64_t num_edges,
+                               int32_t num_nodes, float* out_weight, int32_t* flags_dev,
+                               void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* Destination-sorted CSR of given per-edge values (self loops dropped); rowptr (N+1), col/val (E). */
+int32_t regt_raw_csr(const int64_t* edge_index, const float* edge_value, int64_t num_edges, int32_t num_nodes,
+                     int32_t* rowptr, int32_t* col, float* val, int32_t* flags_dev,
+                     void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* Order-independent 64-bit fingerprint of (edge_index, edge_weight) -- cache key for prepared graphs. */
+int32_t regt_graph_fingerprint(const int64_t* edge_index, const float* edge_weight, int64_t num_edges,
+                               uint64_t* out_dev, regt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sparse aggregation -- MessagePassing.propagate (gather x[row], scale, scatter-add at col) of both
+ * conv types, as a pull over the prepared CSR:  Y[r,:] = sum_e val[e] * X[col[e],:].
+ * X has nrows_x rows, Y nrows rows, both `width` fp32 wide (multiple of 4), 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
+                      int32_t nrows, int32_t nrows_x, int32_t width, regt_stream_t stream);
+
+/* Snapshot layout change (N,F,T) time-innermost (load_dataset.py:451-457) -> (N,T,F) rows. */
+int32_t regt_pack_x(const float* x, float* x_packed, int32_t num_nodes, int32_t num_features, int32_t periods,
+                    regt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense contraction -- torch.nn.Linear / PyG Linear call sites:
+ *   out[M,N] = act(A[M,K] W[N,K]^T + bias)     act: 0 none, 1 leaky_relu(slope), 2 relu
+ * and the matching weight gradient  dW[N,K] = dOut[M,N]^T A[M,K]  (+ optional dbias = column sums).
+ * regt_wgrad needs `slab` of regt_wgrad_slab_floats(...) floats.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t regt_linear(const float* A, int64_t lda, int64_t M, int32_t K, const float* W, int64_t ldw, int32_t N,
+                    const float* bias, int32_t act, float slope, float* out, int64_t ldo, regt_stream_t stream);
+size_t regt_wgrad_slab_floats(int64_t M, int32_t N, int32_t K, int32_t with_bias);
+int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, int64_t M, int32_t N, int32_t K,
+                   float* dW, int64_t ldw, float* dbias, float* slab, regt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model forward / backward.
+ *
+ * regt_dims:  N nodes, T periods, F node features, C hidden (256 in the reference), R regions,
+ *             O output_dim, H1 head hidden (128);  regional = 1 for RegionalTemporalGCN
+ *             (models/RegionalTemporalGCN.py:9-149), 0 for TemporalGCN / A3TGCN (models/TemporalGCN.py:7-91).
+ * regt_graph: stacked CSR with 2N rows -- rows [0,N) = A_hat of the full graph, rows [N,2N) = the
+ *             (merged, node-disjoint) regional scaled Laplacians; node_region (N) = region whose
+ *             Laplacian owns the node's row; chunk_tab (n_chunks,2) = [row_begin,row_end) ranges of
+ *             (node*T + t) rows that lie inside one region, chunk_region (n_chunks) their region.
+ * regt_params: the reference's state_dict tensors (names in comments), read-only.
+ * regt_grads:  same tensors, written (not accumulated) by regt_backward; NULL entries are skipped.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct regt_dims {
+    int32_t N, T, F, C, R, O, H1;
+    int32_t regional;
+    float lrelu_slope;      /* 0.01 (F.leaky_relu default, RegionalTemporalGCN.py:143) */
+} regt_dims;
+
+typedef struct regt_graph {
+    const int32_t* rowptr;        /* (2N+1) */
+    const int32_t* col;
+    const float* val;
+    const int32_t* node_region;   /* (N) */
+    const int32_t* chunk_tab;     /* (n_chunks, 2) */
+    const int32_t* chunk_region;  /* (n_chunks) */
+    int32_t n_chunks;
+} regt_graph;
+
+typedef struct regt_params {
+    const float* attention;      /* tgnn._attention (T) */
+    const float* conv_lin_w[3];  /* tgnn._base_tgcn.conv_{z,r,h}.lin.weight (C,F) */
+    const float* conv_bias[3];   /* tgnn._base_tgcn.conv_{z,r,h}.bias (C) */
+    const float* gate_w[3];      /* tgnn._base_tgcn.linear_{z,r,h}.weight (C,2C) */
+    const float* gate_b[3];      /* tgnn._base_tgcn.linear_{z,r,h}.bias (C) */
+    const float* cheb_w0;        /* tgnn.conv.lins.0.weight (C,F) */
+    const float* cheb_w1;        /* tgnn.conv.lins.1.weight (C,F) */
+    const float* cheb_bias;      /* tgnn.conv.bias (C) */
+    const float* region_w;       /* tgnn.linear.weight (C,R*C)   (regional only) */
+    const float* region_b;       /* tgnn.linear.bias (C)         (regional only) */
+    const float* head1_w;        /* linear1.weight (H1,C) */
+    const float* head1_b;        /* linear1.bias (H1) */
+    const float* head2_w;        /* linear2.weight (O,H1) */
+    const float* head2_b;        /* linear2.bias (O) */
+} regt_params;
+
+typedef struct regt_grads {
+    float* attention;
+    float* conv_lin_w[3];
+    float* conv_bias[3];
+    float* gate_w[3];
+    float* gate_b[3];
+    float* cheb_w0;
+    float* cheb_w1;
+    float* cheb_bias;
+    float* region_w;
+    float* region_b;
+    float* head1_w;
+    float* head1_b;
+    float* head2_w;
+    float* head2_b;
+} regt_grads;
+
+/* Bytes of device workspace regt_forward / regt_backward need (same buffer for both: the forward
+ * leaves the activations the backward reads). */
+size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks);
+
+/* x (N,F,T) -> pred (N,O), hidden (N,C).  RegionalTemporalGCN.forward / TemporalGCN.forward. */
+int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
+                     float* pred, float* hidden, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* Gradients of all parameters given dL/dpred (N,O) and optionally dL/dhidden (N,C) (may be NULL).
+ * Must follow regt_forward on the same workspace; `hidden` is that forward's hidden output. */
+int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
+                      const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
+                      void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* loss = mean((pred - y)^2) over `count` entries with mean taken over `global_count`
+ * (run.py:180); writes dpred = dloss/dpred and the scalar loss. */
+int32_t regt_mse_loss_grad(const float* pred, const float* y, float* dpred, float* loss_out, int64_t count,
+                           int64_t global_count, regt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REGTGCN_H */

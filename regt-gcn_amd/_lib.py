@@ -1,0 +1,102 @@
+"""ctypes binding of libregtgcn_hip.so (C ABI: include/regtgcn.h).
+
+There is no fallback: if the library is missing or a call fails, this module raises.
+PyTorch is used by the callers only to own device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libregtgcn_hip.so")
+ABI_VERSION = 1
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+
+class RegtError(RuntimeError):
+    pass
+
+
+class Dims(C.Structure):
+    _fields_ = [("N", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("R", C.c_int32),
+                ("O", C.c_int32), ("H1", C.c_int32), ("regional", C.c_int32), ("lrelu_slope", C.c_float)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("rowptr", vp), ("col", vp), ("val", vp), ("node_region", vp), ("chunk_tab", vp),
+                ("chunk_region", vp), ("n_chunks", C.c_int32)]
+
+
+_PARAM_FIELDS = [("attention", vp), ("conv_lin_w", vp * 3), ("conv_bias", vp * 3), ("gate_w", vp * 3),
+                 ("gate_b", vp * 3), ("cheb_w0", vp), ("cheb_w1", vp), ("cheb_bias", vp), ("region_w", vp),
+                 ("region_b", vp), ("head1_w", vp), ("head1_b", vp), ("head2_w", vp), ("head2_b", vp)]
+
+
+class Params(C.Structure):
+    _fields_ = _PARAM_FIELDS
+
+
+class Grads(C.Structure):
+    _fields_ = _PARAM_FIELDS
+
+
+# name, restype, argtypes -- one entry per function declared in include/regtgcn.h
+SIGNATURES = {
+    "regt_abi_version": (C.c_int32, []),
+    "regt_last_error": (C.c_char_p, []),
+    "regt_graph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "regt_gcn_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_cheb_edge_weights": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
+    "regt_raw_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_graph_fingerprint": (C.c_int32, [vp, vp, C.c_int64, vp, vp]),
+    "regt_spmm_csr": (C.c_int32, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_pack_x": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_linear": (C.c_int32, [vp, C.c_int64, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, vp, C.c_int32,
+                                C.c_float, vp, C.c_int64, vp]),
+    "regt_wgrad_slab_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "regt_wgrad": (C.c_int32, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp]),
+    "regt_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int32]),
+    "regt_forward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_backward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), C.POINTER(Grads), vp, vp, vp,
+                                  vp, C.c_size_t, vp]),
+    "regt_mse_loss_grad": (C.c_int32, [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RegtError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RegtError(
+            f"{LIB_PATH} not found: the HIP library is not built. Run `python regt-gcn_amd/build.py` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.regt_abi_version()
+    if v != ABI_VERSION:
+        raise RegtError(f"libregtgcn_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().regt_last_error().decode("utf-8", "replace")
+        raise RegtError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None) as a c_void_p value."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,469 @@
+// C ABI (include/regtgcn.h) and the forward / backward pipeline of the RegT-GCN hot path.
+//
+// Formulation (validated against the oracle in tests/test_fused_math.py):
+// every sparse operator of the reference acts on the *input* x, so
+//   * A_hat x and L~ x are aggregated once per snapshot at width T*F (one stacked SpMM) and are
+//     constants w.r.t. the parameters -- the backward pass has no sparse op;
+//   * every weight that multiplies a width-F quantity is folded into a (C,F) "composed" weight
+//     (A0 = (sum_r Wl_r) W0, A_r = Wl_r W1, G_k = U_k[:, :C] V_k), so the only K=C contractions
+//     left are the three hidden-state GEMMs of the GRU cell.
+// Rows of all (M = N*T, .) activations are ordered node-major: m = node*T + t.
+#include <limits.h>
+#include <stdarg.h>
+
+#include "../../include/regtgcn.h"
+#include "kernels.h"
+
+namespace regt {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+namespace {
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+GemmSeg make_seg(const float* A, long lda, const float* B0, const float* B1, long ldb, int nsplit, int K, bool bt,
+                 int extra_flags = 0, long region_stride = 0) {
+    GemmSeg s{};
+    s.A = A; s.lda = lda; s.B0 = B0; s.B1 = B1 ? B1 : B0; s.ldb = ldb; s.nsplit = nsplit; s.K = K;
+    s.b_region_stride = region_stride;
+    int f = extra_flags | (bt ? SEG_BT : 0);
+    if (lda % 4 == 0 && al16(A)) f |= SEG_VEC_A;
+    if (ldb % 4 == 0 && al16(B0) && al16(s.B1) && region_stride % 4 == 0) f |= SEG_VEC_B;
+    s.flags = f;
+    return s;
+}
+
+struct Layout {
+    // saved by forward
+    float *Xp, *AX, *LX, *h, *ZR, *q, *Ht, *y1, *probs;
+    float *A0, *Aall, *bprime, *Gzr, *Gh, *czr, *ch;
+    // backward temporaries
+    float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
+    float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
+    int kchunk, nchunks, kchunk_head, nchunks_head, cb_npb, cb_blocks;
+    size_t bytes;
+};
+
+Layout make_layout(const regt_dims& d, int n_chunks_tab, char* base) {
+    Layout L{};
+    const long N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
+    const long M = N * T;
+    size_t off = 0;
+    auto take = [&](long nfloats) {
+        size_t o = off;
+        off += ((size_t)nfloats * 4 + 255) & ~size_t(255);
+        return base ? reinterpret_cast<float*>(base + o) : nullptr;
+    };
+    L.Xp = take(M * F);
+    L.AX = take(2 * M * F);
+    L.LX = L.AX ? L.AX + M * F : nullptr;
+    L.h = take(M * C);
+    L.ZR = take(M * 2 * C);
+    L.q = take(M * C);
+    L.Ht = take(M * C);
+    L.y1 = take(N * H1);
+    L.probs = take(T);
+    L.A0 = take(C * F);
+    L.Aall = take(R * C * F);
+    L.bprime = take(C);
+    L.Gzr = take(2 * C * F);
+    L.Gh = take(C * F);
+    L.czr = take(2 * C);
+    L.ch = take(C);
+    L.dOH = take(N * C);
+    L.d1 = take(N * H1);
+    L.dhp = take(M * C);
+    L.dzr = take(M * 2 * C);
+    L.dh = take(M * C);
+    long kc = ((M + 255) / 256 + 31) / 32 * 32;
+    if (kc < 512) kc = 512;
+    L.kchunk = (int)kc;
+    L.nchunks = (int)((M + kc - 1) / kc);
+    long kh = ((N + 63) / 64 + 31) / 32 * 32;
+    if (kh < 512) kh = 512;
+    L.kchunk_head = (int)kh;
+    L.nchunks_head = (int)((N + kh - 1) / kh);
+    L.cb_npb = (int)((N + 2047) / 2048);
+    L.cb_npb = (L.cb_npb + 3) / 4 * 4;
+    L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
+    L.dp_partial = take((long)L.cb_blocks * T);
+    long slab = (long)L.nchunks * (2 * C * C + 2 * C);
+    long s2 = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
+    long s3 = (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O);
+    if (s2 > slab) slab = s2;
+    if (s3 > slab) slab = s3;
+    L.slab = take(slab);
+    L.dA0 = take(C * F);
+    L.dAall = take(R * C * F);
+    L.dbprime = take(C);
+    L.dGzr = take(2 * C * F);
+    L.dGh = take(C * F);
+    L.dczr = take(2 * C);
+    L.dch = take(C);
+    L.bytes = off;
+    return L;
+}
+
+int check_dims(const regt_dims* d) {
+    REGT_CHECK_ARG(d != nullptr, "dims is NULL");
+    REGT_CHECK_ARG(d->N > 0 && d->T > 0 && d->F > 0 && d->C > 0 && d->R > 0 && d->O > 0 && d->H1 > 0,
+                   "dims: all of N,T,F,C,R,O,H1 must be positive (N=%d T=%d F=%d C=%d R=%d O=%d H1=%d)", d->N, d->T,
+                   d->F, d->C, d->R, d->O, d->H1);
+    REGT_CHECK_ARG(d->F % 4 == 0, "dims: F=%d must be a multiple of 4 (16-byte feature rows)", d->F);
+    REGT_CHECK_ARG(d->C % 4 == 0, "dims: C=%d must be a multiple of 4", d->C);
+    REGT_CHECK_ARG(d->T <= 64, "dims: T=%d exceeds 64 periods", d->T);
+    REGT_CHECK_ARG((long)d->N * d->T < (1L << 31), "dims: N*T too large");
+    return REGT_OK;
+}
+
+#define TRY(x)               \
+    do {                     \
+        int _rc = (x);       \
+        if (_rc) return _rc; \
+    } while (0)
+
+// C[m x n] = A[m x k] * B[k x n] helper for contiguous-ish operands (strides given explicitly).
+SmallGemm sg(const float* A, long sai, long sak, long sab, const float* B, long sbk, long sbj, long sbb, float* C,
+             long sci, long scj, long scb, int m, int n, int k, int batch, int sum_batch, int accumulate) {
+    return SmallGemm{A, sai, sak, sab, B, sbk, sbj, sbb, C, sci, scj, scb, m, n, k, batch, sum_batch, accumulate};
+}
+
+int compose_forward(const regt_dims& d, const regt_params& p, const Layout& L, hipStream_t st) {
+    const int C = d.C, F = d.F, R = d.R;
+    if (d.regional) {
+        // A0 = sum_r Wl_r W0            (C,F)
+        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_w0, F, 1, 0, L.A0, F, 1, 0, C, F, C, R, 1, 0), st));
+        // A_r = Wl_r W1                 (R,C,F)
+        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_w1, F, 1, 0, L.Aall, F, 1, (long)C * F, C, F, C, R, 0, 0), st));
+        // b' = sum_r Wl_r b_c + b_l
+        REGT_CHECK_HIP(hipMemcpyAsync(L.bprime, p.region_b, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_bias, 1, 0, 0, L.bprime, 1, 0, 0, C, 1, C, R, 1, 1), st));
+    }
+    for (int k = 0; k < 3; ++k) {
+        float* G = k < 2 ? L.Gzr + (long)k * C * F : L.Gh;
+        float* c = k < 2 ? L.czr + (long)k * C : L.ch;
+        // G_k = U_k[:, :C] V_k ;  c_k = U_k[:, :C] beta_k + u_k
+        TRY(launch_small_gemm(sg(p.gate_w[k], 2L * C, 1, 0, p.conv_lin_w[k], F, 1, 0, G, F, 1, 0, C, F, C, 1, 0, 0), st));
+        REGT_CHECK_HIP(hipMemcpyAsync(c, p.gate_b[k], (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+        TRY(launch_small_gemm(sg(p.gate_w[k], 2L * C, 1, 0, p.conv_bias[k], 1, 0, 0, c, 1, 0, 0, C, 1, C, 1, 0, 1), st));
+    }
+    return REGT_OK;
+}
+
+int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, float* pred,
+                 float* hidden, const Layout& L, hipStream_t st) {
+    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
+    const long M = (long)N * T;
+    TRY(launch_softmax_small(p.attention, L.probs, T, st));
+    TRY(compose_forward(d, p, L, st));
+    // 1. pack the snapshot and aggregate: [A_hat; L~] x  (one stacked SpMM over 2N rows, width T*F)
+    TRY(launch_pack_x(x, L.Xp, N, F, T, st));
+    TRY(launch_spmm_csr(g.rowptr, g.col, g.val, L.Xp, L.AX, 2 * N, N, T * F, st));
+    const float* A0 = d.regional ? L.A0 : p.cheb_w0;
+    const float* Aall = d.regional ? L.Aall : p.cheb_w1;
+    const float* bpr = d.regional ? L.bprime : p.cheb_bias;
+    // 2. regional embedding h = act(x A0^T + (L~ x) A_region^T + b')
+    {
+        GemmSegs S{};
+        S.nseg = 2;
+        S.seg[0] = make_seg(L.Xp, F, A0, nullptr, F, INT_MAX, F, true);
+        S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true, R > 1 ? SEG_REGION : 0, (long)C * F);
+        S.node_region = g.node_region;
+        S.row_div = T;
+        EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        TRY(launch_gemm_bias_act(S, M, C, e, st));
+    }
+    // 3. update + reset gates: [Z|R] = sigmoid(h [Uz2;Ur2]^T + (A_hat x) [Gz;Gr]^T + [cz;cr]),  q = h*R
+    {
+        GemmSegs S{};
+        S.nseg = 2;
+        S.seg[0] = make_seg(L.h, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true);
+        S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
+        S.row_div = T;
+        EpiGates e{L.ZR, L.h, L.q, L.czr, C};
+        TRY(launch_gemm_gates(S, M, 2 * C, e, st));
+    }
+    // 4. candidate state, GRU blend and attention-weighted sum over periods -> hidden (N,C)
+    {
+        CandArgs a{};
+        a.S.nseg = 2;
+        a.S.seg[0] = make_seg(L.q, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, true);
+        a.S.seg[1] = make_seg(L.AX, F, L.Gh, nullptr, F, INT_MAX, F, true);
+        a.S.row_div = T;
+        a.num_nodes = N; a.T = T; a.C = C;
+        a.bias = L.ch; a.ZR = L.ZR; a.h = L.h; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
+        TRY(launch_gemm_candidate(a, st));
+    }
+    // 5. head: relu -> linear1 -> relu -> linear2
+    {
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(hidden, C, p.head1_w, nullptr, C, INT_MAX, C, true, SEG_RELU_A);
+        S.row_div = 1;
+        EpiBiasAct e{L.y1, H1, p.head1_b, ACT_RELU, 0.f};
+        TRY(launch_gemm_bias_act(S, N, H1, e, st));
+        GemmSegs S2{};
+        S2.nseg = 1;
+        S2.seg[0] = make_seg(L.y1, H1, p.head2_w, nullptr, H1, INT_MAX, H1, true);
+        S2.row_div = 1;
+        EpiBiasAct e2{pred, O, p.head2_b, ACT_NONE, 0.f};
+        TRY(launch_gemm_bias_act(S2, N, O, e2, st));
+    }
+    return REGT_OK;
+}
+
+// out[Nout x Nin] (+ column sums) = P^T Q over uniform chunks, reduced deterministically.
+int wgrad_full(const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu, long M, int kchunk,
+               int nchunks, float* slab, float* out, long ldo, float* colsum, hipStream_t st) {
+    WgradArgs a{P, ldp, Nout, Q, ldq, Nin, q_relu, M, kchunk, nullptr, nchunks, slab, colsum ? 1 : 0};
+    TRY(launch_wgrad(a, st));
+    WgradReduceArgs r{};
+    r.slab = slab; r.nchunks = nchunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+    r.Nout = Nout; r.Nin = Nin; r.chunk_group = nullptr; r.ngroups = 1; r.out = out; r.ldo = ldo; r.group_stride = 0;
+    r.colsum_out = colsum; r.colsum_offset = (long)Nout * Nin; r.ncolsum = Nout; r.accumulate = 0;
+    return launch_wgrad_reduce(r, st);
+}
+
+int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
+                  const float* dpred, const float* dhidden, const float* hidden, const Layout& L, hipStream_t st) {
+    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
+    const long M = (long)N * T;
+    // ---- head ----------------------------------------------------------------------------------
+    TRY(wgrad_full(dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
+    {   // d1 = (dpred A2) * (y1 > 0)
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(dpred, O, p.head2_w, nullptr, H1, INT_MAX, O, false);
+        S.row_div = 1;
+        EpiMaskAdd e{L.d1, H1, L.y1, H1, nullptr, 0};
+        TRY(launch_gemm_mask_add(S, N, H1, e, st));
+    }
+    TRY(wgrad_full(L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head1_w, C, gr.head1_b, st));
+    {   // dOH = (d1 A1) * (hidden > 0) + dhidden
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(L.d1, H1, p.head1_w, nullptr, C, INT_MAX, H1, false);
+        S.row_div = 1;
+        EpiMaskAdd e{L.dOH, C, hidden, C, dhidden, C};
+        TRY(launch_gemm_mask_add(S, N, C, e, st));
+    }
+    // ---- cell: gate pre-activation gradients ------------------------------------------------------
+    {
+        CellBwdArgs a{L.dOH, L.probs, L.ZR, L.h, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
+        TRY(launch_cell_bwd(a, st));
+        if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
+    }
+    {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
+        S.row_div = T;
+        EpiDgrad1 e{L.h, L.ZR, L.dOH, L.probs, L.dzr, L.dh, C, T};
+        TRY(launch_gemm_dgrad1(S, M, C, e, st));
+    }
+    {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
+        GemmSegs S{};
+        S.nseg = 2;
+        S.seg[0] = make_seg(L.dzr, 2L * C, p.gate_w[0] + C, nullptr, 2L * C, INT_MAX, C, false);
+        S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
+        S.row_div = T;
+        EpiDgrad2 e{L.dh, L.h, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        TRY(launch_gemm_dgrad2(S, M, C, e, st));
+    }
+    // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
+    TRY(wgrad_full(L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
+    TRY(wgrad_full(L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGh, F, nullptr, st));
+    {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
+        WgradArgs a{L.dzr, 2L * C, 2 * C, L.h, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
+        TRY(launch_wgrad(a, st));
+        for (int k = 0; k < 2; ++k) {
+            WgradReduceArgs r{};
+            r.slab = L.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a);
+            r.elem_offset = (long)k * C * C; r.Nout = C; r.Nin = C; r.ngroups = 1;
+            r.out = gr.gate_w[k] + C; r.ldo = 2L * C;
+            r.colsum_out = k == 0 ? L.dczr : nullptr; r.colsum_offset = 2L * C * C; r.ncolsum = 2 * C;
+            TRY(launch_wgrad_reduce(r, st));
+        }
+    }
+    TRY(wgrad_full(L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGzr, F, nullptr, st));
+    float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
+    float* dAall = d.regional ? L.dAall : gr.cheb_w1;
+    float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
+    TRY(wgrad_full(L.dh, C, C, L.Xp, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dA0, F, dbpr, st));
+    if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
+        REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
+        WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, L.slab, 0};
+        TRY(launch_wgrad(a, st));
+        WgradReduceArgs r{};
+        r.slab = L.slab; r.nchunks = g.n_chunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+        r.Nout = C; r.Nin = F; r.chunk_group = g.chunk_region; r.ngroups = R; r.out = dAall; r.ldo = F;
+        r.group_stride = (long)C * F;
+        TRY(launch_wgrad_reduce(r, st));
+    } else {
+        TRY(wgrad_full(L.dh, C, C, L.LX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dAall, F, nullptr, st));
+    }
+    // ---- back through the weight compositions (tiny) --------------------------------------------------
+    for (int k = 0; k < 3; ++k) {
+        const float* dG = k < 2 ? L.dGzr + (long)k * C * F : L.dGh;
+        const float* dc = k < 2 ? L.dczr + (long)k * C : L.dch;
+        // dU_k[:, :C] = dG_k V_k^T + dc_k beta_k^T
+        TRY(launch_small_gemm(sg(dG, F, 1, 0, p.conv_lin_w[k], 1, F, 0, gr.gate_w[k], 2L * C, 1, 0, C, C, F, 1, 0, 0), st));
+        TRY(launch_small_gemm(sg(dc, 1, 0, 0, p.conv_bias[k], 0, 1, 0, gr.gate_w[k], 2L * C, 1, 0, C, C, 1, 1, 0, 1), st));
+        // dV_k = U_k[:, :C]^T dG_k ; dbeta_k = U_k[:, :C]^T dc_k ; du_k = dc_k
+        TRY(launch_small_gemm(sg(p.gate_w[k], 1, 2L * C, 0, dG, F, 1, 0, gr.conv_lin_w[k], F, 1, 0, C, F, C, 1, 0, 0), st));
+        TRY(launch_small_gemm(sg(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, gr.conv_bias[k], 1, 0, 0, C, 1, C, 1, 0, 0), st));
+        REGT_CHECK_HIP(hipMemcpyAsync(gr.gate_b[k], dc, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (d.regional) {
+        const long RC = (long)R * C;
+        // dWl_r = dA_r W1^T + dA0 W0^T + db' b_c^T
+        TRY(launch_small_gemm(sg(L.dAall, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, gr.region_w, RC, 1, C, C, C, F, R, 0, 0), st));
+        TRY(launch_small_gemm(sg(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, gr.region_w, RC, 1, C, C, C, F, R, 0, 1), st));
+        TRY(launch_small_gemm(sg(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, gr.region_w, RC, 1, C, C, C, 1, R, 0, 1), st));
+        // dW0 = (sum_r Wl_r)^T dA0 ; dW1 = sum_r Wl_r^T dA_r ; db_c = (sum_r Wl_r)^T db' ; db_l = db'
+        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dA0, F, 1, 0, gr.cheb_w0, F, 1, 0, C, F, C, R, 1, 0), st));
+        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dAall, F, 1, (long)C * F, gr.cheb_w1, F, 1, 0, C, F, C, R, 1, 0), st));
+        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dbprime, 1, 0, 0, gr.cheb_bias, 1, 0, 0, C, 1, C, R, 1, 0), st));
+        REGT_CHECK_HIP(hipMemcpyAsync(gr.region_b, L.dbprime, (size_t)C * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return REGT_OK;
+}
+
+int check_ptrs(const regt_params* p, const regt_dims& d) {
+    REGT_CHECK_ARG(p != nullptr, "params is NULL");
+    bool ok = p->attention && p->cheb_w0 && p->cheb_w1 && p->cheb_bias && p->head1_w && p->head1_b && p->head2_w && p->head2_b;
+    for (int k = 0; k < 3; ++k) ok = ok && p->conv_lin_w[k] && p->conv_bias[k] && p->gate_w[k] && p->gate_b[k];
+    if (d.regional) ok = ok && p->region_w && p->region_b;
+    REGT_CHECK_ARG(ok, "params: a required tensor pointer is NULL");
+    return REGT_OK;
+}
+
+}  // namespace
+}  // namespace regt
+
+using namespace regt;
+
+extern "C" {
+
+int32_t regt_abi_version(void) { return REGT_ABI_VERSION; }
+const char* regt_last_error(void) { return g_err; }
+
+size_t regt_graph_workspace_bytes(int64_t E, int32_t N) { return graph_workspace_bytes((long)E, N); }
+
+int32_t regt_gcn_csr(const int64_t* ei, const float* w, int64_t E, int32_t N, int32_t* rowptr, int32_t* col, float* val,
+                     int32_t* flags_dev, void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && rowptr && col && val && flags_dev && ws, "regt_gcn_csr: NULL pointer");
+    return graph_gcn_csr(ei, w, (long)E, N, rowptr, col, val, flags_dev, ws, ws_bytes, (hipStream_t)st);
+}
+
+int32_t regt_cheb_edge_weights(const int64_t* ei, const float* w, int64_t E, int32_t N, float* out, int32_t* flags_dev,
+                               void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && (out || E == 0) && flags_dev && ws, "regt_cheb_edge_weights: NULL pointer");
+    return graph_cheb_edge_weights(ei, w, (long)E, N, out, flags_dev, ws, ws_bytes, (hipStream_t)st);
+}
+
+int32_t regt_raw_csr(const int64_t* ei, const float* v, int64_t E, int32_t N, int32_t* rowptr, int32_t* col, float* val,
+                     int32_t* flags_dev, void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && rowptr && col && val && flags_dev && ws, "regt_raw_csr: NULL pointer");
+    return graph_raw_csr(ei, v, (long)E, N, rowptr, col, val, flags_dev, ws, ws_bytes, (hipStream_t)st);
+}
+
+int32_t regt_graph_fingerprint(const int64_t* ei, const float* w, int64_t E, uint64_t* out_dev, regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && out_dev, "regt_graph_fingerprint: NULL pointer");
+    return graph_fingerprint(ei, w, (long)E, reinterpret_cast<unsigned long long*>(out_dev), (hipStream_t)st);
+}
+
+int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y, int32_t nrows,
+                      int32_t nrows_x, int32_t width, regt_stream_t st) {
+    REGT_CHECK_ARG(rowptr && col && val && X && Y, "regt_spmm_csr: NULL pointer");
+    return launch_spmm_csr(rowptr, col, val, X, Y, nrows, nrows_x, width, (hipStream_t)st);
+}
+
+int32_t regt_pack_x(const float* x, float* xp, int32_t N, int32_t F, int32_t T, regt_stream_t st) {
+    REGT_CHECK_ARG(x && xp && N > 0 && F > 0 && T > 0, "regt_pack_x: bad argument");
+    return launch_pack_x(x, xp, N, F, T, (hipStream_t)st);
+}
+
+int32_t regt_linear(const float* A, int64_t lda, int64_t M, int32_t K, const float* W, int64_t ldw, int32_t N,
+                    const float* bias, int32_t act, float slope, float* out, int64_t ldo, regt_stream_t st) {
+    REGT_CHECK_ARG(A && W && out && M > 0 && K > 0 && N > 0, "regt_linear: bad argument");
+    REGT_CHECK_ARG(act >= 0 && act <= 2, "regt_linear: act must be 0, 1 or 2");
+    GemmSegs S{};
+    S.nseg = 1;
+    S.seg[0] = make_seg(A, lda, W, nullptr, ldw, INT_MAX, K, true);
+    S.row_div = 1;
+    EpiBiasAct e{out, ldo, bias, act, slope};
+    return launch_gemm_bias_act(S, M, N, e, (hipStream_t)st);
+}
+
+static void wgrad_chunks(int64_t M, int* kchunk, int* nchunks) {
+    long kc = ((M + 255) / 256 + 31) / 32 * 32;
+    if (kc < 512) kc = 512;
+    *kchunk = (int)kc;
+    *nchunks = (int)((M + kc - 1) / kc);
+}
+
+size_t regt_wgrad_slab_floats(int64_t M, int32_t N, int32_t K, int32_t with_bias) {
+    int kc, nc;
+    wgrad_chunks(M, &kc, &nc);
+    return (size_t)nc * ((size_t)N * K + (with_bias ? N : 0));
+}
+
+int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, int64_t M, int32_t N, int32_t K, float* dW,
+                   int64_t ldw, float* dbias, float* slab, regt_stream_t st) {
+    REGT_CHECK_ARG(dOut && A && dW && slab && M > 0 && N > 0 && K > 0, "regt_wgrad: bad argument");
+    int kc, nc;
+    wgrad_chunks(M, &kc, &nc);
+    return wgrad_full(dOut, ldd, N, A, lda, K, 0, M, kc, nc, slab, dW, ldw, dbias, (hipStream_t)st);
+}
+
+size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks) {
+    if (check_dims(dims)) return 0;
+    return make_layout(*dims, n_chunks, nullptr).bytes;
+}
+
+int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x, float* pred,
+                     float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+    TRY(check_dims(dims));
+    REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && graph->node_region, "regt_forward: graph incomplete");
+    TRY(check_ptrs(params, *dims));
+    REGT_CHECK_ARG(x && pred && hidden && ws, "regt_forward: NULL pointer");
+    REGT_CHECK_ARG(al16(x) && al16(hidden) && al16(ws), "regt_forward: x, hidden and workspace must be 16-byte aligned");
+    Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    return forward_impl(*dims, *graph, *params, x, pred, hidden, L, (hipStream_t)st);
+}
+
+int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const regt_grads* grads,
+                      const float* dpred, const float* dhidden, const float* hidden, void* ws, size_t ws_bytes,
+                      regt_stream_t st) {
+    TRY(check_dims(dims));
+    REGT_CHECK_ARG(graph && graph->rowptr && graph->node_region, "regt_backward: graph incomplete");
+    TRY(check_ptrs(params, *dims));
+    REGT_CHECK_ARG(grads && dpred && hidden && ws, "regt_backward: NULL pointer");
+    {
+        const regt_grads& g = *grads;
+        bool ok = g.cheb_w0 && g.cheb_w1 && g.cheb_bias && g.head1_w && g.head1_b && g.head2_w && g.head2_b;
+        for (int k = 0; k < 3; ++k) ok = ok && g.conv_lin_w[k] && g.conv_bias[k] && g.gate_w[k] && g.gate_b[k];
+        if (dims->regional) ok = ok && g.region_w && g.region_b;
+        REGT_CHECK_ARG(ok, "regt_backward: a required gradient pointer is NULL (only `attention` may be NULL)");
+    }
+    Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, L, (hipStream_t)st);
+}
+
+int32_t regt_mse_loss_grad(const float* pred, const float* y, float* dpred, float* loss_out, int64_t count,
+                           int64_t global_count, regt_stream_t st) {
+    REGT_CHECK_ARG(pred && y && count > 0 && global_count > 0, "regt_mse_loss_grad: bad argument");
+    return launch_mse_grad(pred, y, dpred, loss_out, (long)count, 1.0f / (float)global_count, (hipStream_t)st);
+}
+
+}  // extern "C"

@@ -1,0 +1,375 @@
+// Dense contractions of the RegT-GCN pipeline on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   gemm_flat_kernel<Epi>   C = sum_seg A_seg B_seg^T with a fused epilogue   (forward + dgrad)
+//   gemm_cand_kernel        candidate state + GRU blend + attention-weighted sum over T periods
+//   wgrad_kernel<..>        out = P^T Q over row chunks (weight gradients), partial slabs
+//   wgrad_reduce_kernel     deterministic reduction of the slabs
+//   small_gemm_kernel       strided batched C = A B for the (C x F)-sized weight compositions
+#include "kernels.h"
+
+namespace regt {
+
+// ---- epilogue functors --------------------------------------------------------------------------
+struct EpiBiasActF {
+    EpiBiasAct e;
+    __device__ __forceinline__ void operator()(long m, int c, float v) const {
+        v += e.bias ? e.bias[c] : 0.f;
+        if (e.act == ACT_LRELU) v = v > 0.f ? v : v * e.slope;
+        else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
+        e.out[m * e.ldo + c] = v;
+    }
+};
+struct EpiGatesF {
+    EpiGates e;
+    __device__ __forceinline__ void operator()(long m, int c, float v) const {
+        float g = 1.0f / (1.0f + expf(-(v + e.bias[c])));
+        e.ZR[m * (2L * e.C) + c] = g;
+        if (c >= e.C) {
+            int cc = c - e.C;
+            e.q[m * e.C + cc] = e.h[m * e.C + cc] * g;
+        }
+    }
+};
+struct EpiDgrad1F {
+    EpiDgrad1 e;
+    __device__ __forceinline__ void operator()(long m, int c, float v) const {
+        long node = m / e.T;
+        int t = (int)(m - node * e.T);
+        float hv = e.h[m * e.C + c];
+        float Z = e.ZR[m * (2L * e.C) + c];
+        float R = e.ZR[m * (2L * e.C) + e.C + c];
+        e.dzr[m * (2L * e.C) + e.C + c] = v * hv * (R * (1.0f - R));
+        e.dh[m * e.C + c] = v * R + e.probs[t] * e.dOH[node * e.C + c] * Z;
+    }
+};
+struct EpiDgrad2F {
+    EpiDgrad2 e;
+    __device__ __forceinline__ void operator()(long m, int c, float v) const {
+        long i = m * e.C + c;
+        float d = e.dh[i] + v;
+        if (e.act == ACT_LRELU) d = e.h[i] > 0.f ? d : d * e.slope;
+        e.dh[i] = d;
+    }
+};
+struct EpiMaskAddF {
+    EpiMaskAdd e;
+    __device__ __forceinline__ void operator()(long m, int c, float v) const {
+        float o = e.mask[m * e.ldm + c] > 0.f ? v : 0.f;
+        if (e.add) o += e.add[m * e.ldadd + c];
+        e.out[m * e.ldo + c] = o;
+    }
+};
+
+template <class EpiF>
+__global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, int N, EpiF epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    GemmCore core(S, rm, n0, N, lds);
+    core.find_regions();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    core.run(acc);
+    core.for_each(acc, [&](int r, int c, float v) { epi(m0 + r, c, v); });
+}
+
+template <class EpiF>
+static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, hipStream_t st) {
+    REGT_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%ld N=%d", M, N);
+    long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
+    REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
+    static bool attr_set = false;
+    (void)attr_set;
+    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_flat_kernel<EpiF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_flat_kernel<EpiF>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, S, M, N, f);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st) {
+    return launch_flat(S, M, N, EpiBiasActF{e}, st);
+}
+int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st) {
+    REGT_CHECK_ARG(N == 2 * e.C, "gates gemm expects N == 2C");
+    return launch_flat(S, M, N, EpiGatesF{e}, st);
+}
+int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
+    REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
+    return launch_flat(S, M, N, EpiDgrad1F{e}, st);
+}
+int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
+    REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");
+    return launch_flat(S, M, N, EpiDgrad2F{e}, st);
+}
+int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, hipStream_t st) {
+    return launch_flat(S, M, N, EpiMaskAddF{e}, st);
+}
+
+// ---- candidate state, T loop inside the workgroup ------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (a.C + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int i0 = (bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
+    f32x16 acc[2][2], oh[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oh[i][j][r] = 0.f;
+    const long C = a.C;
+    for (int t = 0; t < a.T; ++t) {
+        RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
+        GemmCore core(a.S, rm, n0, a.C, lds);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        core.run(acc);
+        const float pt = a.probs[t];
+        core.for_each2(acc, oh, [&](int r, int c, float v, float o) {
+            long m = rm.grow(r);
+            float ht = tanhf(v + a.bias[c]);
+            a.Ht[m * C + c] = ht;
+            float Z = a.ZR[m * 2 * C + c];
+            float hv = a.h[m * C + c];
+            return o + pt * (Z * hv + (1.0f - Z) * ht);
+        });
+    }
+    RowMap rm{(long)i0, 1, nvalid};
+    GemmCore core(a.S, rm, n0, a.C, lds);
+    core.for_each(oh, [&](int r, int c, float v) { a.OH[(long)(i0 + r) * C + c] = v; });
+}
+
+int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
+    REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
+    long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
+    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+    hipLaunchKernelGGL(gemm_cand_kernel, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+// ---- weight gradients: out[Nout x Nin] = P^T Q ----------------------------------------------------
+// Tile 128 (Nout) x BNW (Nin), K = rows of P/Q.  Both operands are staged k-major ([k][i]) exactly
+// as they lie in HBM (row m contiguous along i), read back with conflict-free ds_read_b32.
+constexpr int W_BK = 32;
+constexpr int W_LDP = 128 + 4;
+
+template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 128 ? 2 : 1;
+    constexpr int LDQ = BNW + 4;
+    constexpr int P_TILE = W_BK * W_LDP, Q_TILE = W_BK * LDQ;
+    constexpr int QSLOTS = (W_BK * BNW / 4) / 256;          // float4 slots per thread for Q (4 or 1)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = BNW == 128 ? (wid >> 1) : wid, wc = BNW == 128 ? (wid & 1) : 0;
+    const int tiles_i = (a.Nout + 127) / 128, tiles_j = (a.Nin + BNW - 1) / BNW;
+    const int tile = blockIdx.x % (tiles_i * tiles_j), chunk = blockIdx.x / (tiles_i * tiles_j);
+    const int i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * BNW;
+    long r0, r1;
+    if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
+    else { r0 = (long)chunk * a.kchunk; r1 = r0 + a.kchunk < a.M ? r0 + a.kchunk : a.M; }
+    const bool vecP = (a.ldp % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.P) & 15) == 0);
+    const bool vecQ = (a.ldq % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.Q) & 15) == 0);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+
+    auto load = [&](long k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int slot = tid + 256 * s;
+            long m = k0 + (slot >> 5);
+            int i = i0 + 4 * (slot & 31);
+            rp[s] = (m < r1 && i < a.Nout) ? ld4_guard(a.P + m * a.ldp + i, a.Nout - i, vecP) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < QSLOTS; ++s) {
+            int slot = tid + 256 * s;
+            long m = k0 + slot / (BNW / 4);
+            int j = j0 + 4 * (slot % (BNW / 4));
+            float4 v = (m < r1 && j < a.Nin) ? ld4_guard(a.Q + m * a.ldq + j, a.Nin - j, vecQ) : make_float4(0, 0, 0, 0);
+            if (a.q_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            rq[s] = v;
+        }
+    };
+    auto store = [&](int stage, const float4 (&rp)[4], const float4 (&rq)[QSLOTS]) {
+        float* lp = lds + stage * (P_TILE + Q_TILE);
+        float* lq = lp + P_TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int slot = tid + 256 * s;
+            *reinterpret_cast<float4*>(lp + (slot >> 5) * W_LDP + 4 * (slot & 31)) = rp[s];
+        }
+#pragma unroll
+        for (int s = 0; s < QSLOTS; ++s) {
+            int slot = tid + 256 * s;
+            *reinterpret_cast<float4*>(lq + (slot / (BNW / 4)) * LDQ + 4 * (slot % (BNW / 4))) = rq[s];
+        }
+    };
+    auto compute = [&](int stage) {
+        const float* lp = lds + stage * (P_TILE + Q_TILE);
+        const float* lq = lp + P_TILE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kg * 8 + lh * 4 + j;
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) av[mi] = lp[k * W_LDP + wr * (32 * WM) + mi * 32 + lr];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) bv[ni] = lq[k * LDQ + wc * (32 * WN) + ni * 32 + lr];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (a.colsum && j0 == 0 && tid < 128) {
+#pragma unroll 8
+            for (int k = 0; k < W_BK; ++k) csum += lp[k * W_LDP + tid];
+        }
+    };
+
+    const long nit = (r1 - r0 + W_BK - 1) / W_BK;
+    if (nit > 0) {
+        float4 rp[4], rq[QSLOTS];
+        load(r0, rp, rq);
+        store(0, rp, rq);
+        __syncthreads();
+        for (long it = 0; it < nit; ++it) {
+            const bool more = it + 1 < nit;
+            if (more) load(r0 + (it + 1) * W_BK, rp, rq);
+            compute((int)(it & 1));
+            if (more) store((int)((it + 1) & 1), rp, rq);
+            __syncthreads();
+        }
+    }
+    const long stride = (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0);
+    float* out = a.slab + (long)chunk * stride;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int i = i0 + wr * (32 * WM) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (i < a.Nout) {
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    int j = j0 + wc * (32 * WN) + ni * 32 + lr;
+                    if (j < a.Nin) out[(long)i * a.Nin + j] = acc[mi][ni][reg];
+                }
+            }
+        }
+    if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum;
+}
+
+long wgrad_slab_stride(const WgradArgs& a) { return (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0); }
+
+int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    REGT_CHECK_ARG(a.Nout > 0 && a.Nin > 0 && a.nchunks > 0, "wgrad: empty problem");
+    const bool wide = a.Nin > 32;
+    const int bnw = wide ? 128 : 32;
+    long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
+    REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
+    size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
+    if (wide) {
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<128>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    }
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+__global__ void wgrad_reduce_kernel(WgradReduceArgs a) {
+    const long per = (long)a.Nout * a.Nin;
+    const long total = per * a.ngroups;
+    const long ncs = a.colsum_out ? a.ncolsum : 0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + ncs; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < total) {
+            int g = (int)(idx / per);
+            long e = idx - (long)g * per;
+            float s = 0.f;
+            for (int c = 0; c < a.nchunks; ++c)
+                if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + e];
+            int i = (int)(e / a.Nin), j = (int)(e % a.Nin);
+            float* o = a.out + (long)g * a.group_stride + (long)i * a.ldo + j;
+            *o = a.accumulate ? *o + s : s;
+        } else {
+            int i = (int)(idx - total);
+            float s = 0.f;
+            for (int c = 0; c < a.nchunks; ++c) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + i];
+            a.colsum_out[i] = a.accumulate ? a.colsum_out[i] + s : s;
+        }
+    }
+}
+
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
+    REGT_CHECK_ARG(!(a.colsum_out && a.ngroups != 1), "wgrad_reduce: colsum only with one group");
+    long total = (long)a.Nout * a.Nin * a.ngroups + (a.colsum_out ? a.ncolsum : 0);
+    int blocks = cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+// ---- tiny strided batched GEMM --------------------------------------------------------------------
+__global__ void small_gemm_kernel(SmallGemm g) {
+    const long per = (long)g.m * g.n;
+    const int nb = g.sum_batch ? 1 : g.batch;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per * nb; idx += (long)gridDim.x * blockDim.x) {
+        int b = (int)(idx / per);
+        long e = idx - (long)b * per;
+        int i = (int)(e / g.n), j = (int)(e % g.n);     // j fastest: coalesced when scj == 1 / sbj == 1
+        float s = 0.f;
+        const int b0 = g.sum_batch ? 0 : b, b1 = g.sum_batch ? g.batch : b + 1;
+        for (int bb = b0; bb < b1; ++bb) {
+            const float* A = g.A + (long)bb * g.sab + (long)i * g.sai;
+            const float* B = g.B + (long)bb * g.sbb + (long)j * g.sbj;
+            for (int k = 0; k < g.k; ++k) s += A[(long)k * g.sak] * B[(long)k * g.sbk];
+        }
+        float* c = g.C + (long)b * g.scb + (long)i * g.sci + (long)j * g.scj;
+        *c = g.accumulate ? *c + s : s;
+    }
+}
+
+int launch_small_gemm(const SmallGemm& g, hipStream_t st) {
+    REGT_CHECK_ARG(g.m > 0 && g.n > 0 && g.batch > 0, "small_gemm: empty problem");
+    long total = (long)g.m * g.n * (g.sum_batch ? 1 : g.batch);
+    int blocks = cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(blocks), dim3(256), 0, st, g);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+}  // namespace regt

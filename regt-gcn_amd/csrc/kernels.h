@@ -1,0 +1,116 @@
+// Internal C++ launcher interface of the regtgcn HIP library (not exported; see include/regtgcn.h
+// for the C ABI).  Every launcher enqueues on the given stream and returns REGT_OK / error code.
+#pragma once
+#include "gemm_core.h"
+
+namespace regt {
+
+// ---- epilogue descriptors for the flat segmented GEMM ------------------------------------------
+enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2 };
+
+struct EpiBiasAct {     // out[m, c] = act(v + bias[c])
+    float* out; long ldo; const float* bias; int act; float slope;
+};
+struct EpiGates {       // N = 2C: c <  C: Z = sigmoid(v + b) -> ZR[m, c]
+    float* ZR;          //         c >= C: R = sigmoid(v + b) -> ZR[m, c], q[m, c-C] = h[m, c-C] * R
+    const float* h; float* q; const float* bias; int C;
+};
+struct EpiDgrad1 {      // v = dq[m, c]:  dzr[m, C+c] = v*h*R*(1-R);  dh[m, c] = v*R + p[t]*dOH[node, c]*Z
+    const float* h; const float* ZR; const float* dOH; const float* probs;
+    float* dzr; float* dh; int C; int T;
+};
+struct EpiDgrad2 {      // ds[m, c] = (dh[m, c] + v) * act'(h[m, c])   (in place on dh)
+    float* dh; const float* h; int C; int act; float slope;
+};
+struct EpiMaskAdd {     // out[m, c] = v * (mask[m, c] > 0) + (add ? add[m, c] : 0)
+    float* out; long ldo; const float* mask; long ldm; const float* add; long ldadd;
+};
+
+int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st);
+int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st);
+int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st);
+int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st);
+int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, hipStream_t st);
+
+// Candidate-state GEMM with the loop over the T periods inside the workgroup:
+//   for t: Ht = tanh(q_t Uh2^T + ax_t Gh^T + ch);  Hn = Z*h + (1-Z)*Ht;  OH += p[t]*Hn
+struct CandArgs {
+    GemmSegs S;             // segments with A rows addressed as (node*T + t)
+    int num_nodes, T, C;
+    const float* bias;      // ch (C)
+    const float* ZR;        // (M, 2C)
+    const float* h;         // (M, C)
+    const float* probs;     // (T)
+    float* Ht;              // (M, C) out
+    float* OH;              // (num_nodes, C) out
+};
+int launch_gemm_candidate(const CandArgs& a, hipStream_t st);
+
+// ---- weight-gradient GEMM: out[Nout x Nin] = P^T Q, split over row chunks ----------------------
+struct WgradArgs {
+    const float* P; long ldp; int Nout;
+    const float* Q; long ldq; int Nin;
+    int q_relu;               // apply relu to Q while staging
+    long M;                   // rows
+    int kchunk;               // rows per chunk (uniform) when chunk_tab == nullptr
+    const int* chunk_tab;     // optional (nchunks, 2) [row_start, row_end)
+    int nchunks;
+    float* slab;              // (nchunks, Nout*Nin + (colsum ? Nout : 0))
+    int colsum;               // also produce column sums of P (bias gradient)
+};
+int launch_wgrad(const WgradArgs& a, hipStream_t st);
+long wgrad_slab_stride(const WgradArgs& a);
+
+struct WgradReduceArgs {
+    const float* slab; int nchunks; long slab_stride;
+    long elem_offset;         // first slab element of the (Nout x Nin) block to reduce
+    int Nout, Nin;
+    const int* chunk_group;   // optional (nchunks): output group of each chunk
+    int ngroups;
+    float* out; long ldo; long group_stride;   // out[g*group_stride + i*ldo + j]
+    float* colsum_out;        // optional (ncolsum), only ngroups == 1
+    long colsum_offset;       // slab element of the first column sum
+    int ncolsum;
+    int accumulate;           // add into out instead of overwrite
+};
+int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
+
+// ---- tiny strided batched GEMM (weight composition and its backward) ---------------------------
+//   C[b][i, j] (+)= sum_over_batch? sum_k A[b][i, k] * B[b][k, j]      arbitrary strides
+struct SmallGemm {
+    const float* A; long sai, sak, sab;
+    const float* B; long sbk, sbj, sbb;
+    float* C; long sci, scj, scb;
+    int m, n, k, batch;
+    int sum_batch;     // 1: reduce over the batch index into one C
+    int accumulate;    // 1: C += result
+};
+int launch_small_gemm(const SmallGemm& g, hipStream_t st);
+
+// ---- graph preparation (graph.hip) ---------------------------------------------------------------
+size_t graph_workspace_bytes(long E, int N);
+int graph_gcn_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,
+                  int* flags_out_dev, void* ws, size_t ws_bytes, hipStream_t st);
+int graph_cheb_edge_weights(const int64_t* ei, const float* w, long E, int N, float* out_w, int* flags_out_dev,
+                            void* ws, size_t ws_bytes, hipStream_t st);
+int graph_raw_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,
+                  int* flags_out_dev, void* ws, size_t ws_bytes, hipStream_t st);
+int graph_fingerprint(const int64_t* ei, const float* w, long E, unsigned long long* out_dev, hipStream_t st);
+
+// ---- sparse aggregation ------------------------------------------------------------------------
+int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st);            // (N,F,T) -> (N,T,F)
+int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const float* X, float* Y,
+                    int nrows, int nrows_x, int W, hipStream_t st);                              // Y[r] = sum val*X[col]
+
+// ---- cell backward head / small element-wise kernels -------------------------------------------
+int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
+struct CellBwdArgs {
+    const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;
+    float* dhp; float* dzr; float* dp_partial; int num_nodes, T, C; int nodes_per_block;
+};
+int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st);
+int cell_bwd_blocks(int num_nodes, int nodes_per_block);
+int launch_att_bwd(const float* dp_partial, int nblocks, const float* probs, float* datt, int T, hipStream_t st);
+int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st);
+
+}  // namespace regt

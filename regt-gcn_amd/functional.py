@@ -1,0 +1,139 @@
+"""autograd bridge: one Function = one regt_forward / regt_backward pair of the C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .graph import PreparedGraph
+
+HEAD_HIDDEN = 128
+
+# canonical parameter order handed to the Function (state_dict names of the reference)
+GATES = ("z", "r", "h")
+PARAM_NAMES_COMMON = (
+    ["tgnn._attention"]
+    + [f"tgnn._base_tgcn.conv_{k}.lin.weight" for k in GATES]
+    + [f"tgnn._base_tgcn.conv_{k}.bias" for k in GATES]
+    + [f"tgnn._base_tgcn.linear_{k}.weight" for k in GATES]
+    + [f"tgnn._base_tgcn.linear_{k}.bias" for k in GATES]
+    + ["tgnn.conv.lins.0.weight", "tgnn.conv.lins.1.weight", "tgnn.conv.bias"]
+)
+PARAM_NAMES_REGION = ["tgnn.linear.weight", "tgnn.linear.bias"]
+PARAM_NAMES_HEAD = ["linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias"]
+
+
+def param_names(regional: bool) -> List[str]:
+    return PARAM_NAMES_COMMON + (PARAM_NAMES_REGION if regional else []) + PARAM_NAMES_HEAD
+
+
+def _fill(struct, tensors: Dict[str, Optional[torch.Tensor]], regional: bool):
+    g = lambda n: None if tensors.get(n) is None else tensors[n].data_ptr()
+    struct.attention = g("tgnn._attention")
+    for i, k in enumerate(GATES):
+        struct.conv_lin_w[i] = g(f"tgnn._base_tgcn.conv_{k}.lin.weight")
+        struct.conv_bias[i] = g(f"tgnn._base_tgcn.conv_{k}.bias")
+        struct.gate_w[i] = g(f"tgnn._base_tgcn.linear_{k}.weight")
+        struct.gate_b[i] = g(f"tgnn._base_tgcn.linear_{k}.bias")
+    struct.cheb_w0 = g("tgnn.conv.lins.0.weight")
+    struct.cheb_w1 = g("tgnn.conv.lins.1.weight")
+    struct.cheb_bias = g("tgnn.conv.bias")
+    struct.region_w = g("tgnn.linear.weight") if regional else None
+    struct.region_b = g("tgnn.linear.bias") if regional else None
+    struct.head1_w = g("linear1.weight")
+    struct.head1_b = g("linear1.bias")
+    struct.head2_w = g("linear2.weight")
+    struct.head2_b = g("linear2.bias")
+    return struct
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
+    tab, reg, n = graph.chunks_for(periods)
+    g = _lib.Graph()
+    g.rowptr, g.col, g.val = graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.val.data_ptr()
+    g.node_region = graph.node_region.data_ptr()
+    g.chunk_tab, g.chunk_region, g.n_chunks = tab.data_ptr(), reg.data_ptr(), n
+    return g
+
+
+class RegTGCNFunction(torch.autograd.Function):
+    """(x, *params) -> (pred (N,O), hidden (N,C)); whole-model forward and backward in HIP."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, graph: PreparedGraph, regional: bool, slope: float, *params: torch.Tensor):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.RegtError("RegT-GCN forward needs CUDA/HIP tensors: there is no CPU path in this package")
+        if x.dtype != torch.float32 or x.dim() != 3:
+            raise ValueError(f"x must be float32 (N,F,T), got {x.dtype} {tuple(x.shape)}")
+        names = param_names(regional)
+        if len(params) != len(names):
+            raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
+        for n_, p_ in zip(names, params):
+            if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
+                raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
+        x = x.contiguous()
+        N, F, T = x.shape
+        if N != graph.num_nodes:
+            raise ValueError(f"x has {N} nodes but the prepared graph has {graph.num_nodes}")
+        tens = dict(zip(names, params))
+        Cdim = tens["tgnn.conv.bias"].numel()
+        O = tens["linear2.weight"].shape[0]
+        H1 = tens["linear1.weight"].shape[0]
+        R = graph.num_regions
+        expect = {"tgnn._attention": (T,), "tgnn.conv.lins.0.weight": (Cdim, F), "tgnn.conv.lins.1.weight": (Cdim, F),
+                  "linear1.weight": (H1, Cdim), "linear2.weight": (O, H1)}
+        for k in GATES:
+            expect[f"tgnn._base_tgcn.conv_{k}.lin.weight"] = (Cdim, F)
+            expect[f"tgnn._base_tgcn.linear_{k}.weight"] = (Cdim, 2 * Cdim)
+        if regional:
+            expect["tgnn.linear.weight"] = (Cdim, R * Cdim)
+        for k, shp in expect.items():
+            if tuple(tens[k].shape) != shp:
+                raise ValueError(f"parameter {k} has shape {tuple(tens[k].shape)}, expected {shp}")
+        dims = _lib.Dims(N, T, F, Cdim, R, O, H1, 1 if regional else 0, float(slope))
+        gs = _graph_struct(graph, T)
+        wsb = lib.regt_workspace_bytes(C.byref(dims), gs.n_chunks)
+        if wsb == 0:
+            _lib.check(1, "regt_workspace_bytes")
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        pred = torch.empty(N, O, dtype=torch.float32, device=x.device)
+        hidden = torch.empty(N, Cdim, dtype=torch.float32, device=x.device)
+        ps = _fill(_lib.Params(), tens, regional)
+        _lib.check(lib.regt_forward(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), _lib.ptr(pred), _lib.ptr(hidden),
+                                    _lib.ptr(ws), wsb, _stream()), "regt_forward")
+        ctx.graph, ctx.regional, ctx.dims, ctx.ws, ctx.wsb = graph, regional, dims, ws, wsb
+        ctx.names = names
+        ctx.save_for_backward(hidden, *params)
+        return pred, hidden
+
+    @staticmethod
+    def backward(ctx, dpred, dhidden):
+        lib = _lib.load()
+        hidden, *params = ctx.saved_tensors
+        names, regional, dims = ctx.names, ctx.regional, ctx.dims
+        tens = dict(zip(names, params))
+        dev = hidden.device
+        if dpred is None:
+            dpred = torch.zeros(dims.N, dims.O, dtype=torch.float32, device=dev)
+        dpred = dpred.contiguous()
+        dhid = None if dhidden is None else dhidden.contiguous()
+        grads = {n_: torch.empty_like(p_) for n_, p_ in tens.items()}
+        gs = _graph_struct(ctx.graph, dims.T)
+        ps = _fill(_lib.Params(), tens, regional)
+        gr = _fill(_lib.Grads(), grads, regional)
+        _lib.check(lib.regt_backward(C.byref(dims), C.byref(gs), C.byref(ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
+                                     _lib.ptr(hidden), _lib.ptr(ctx.ws), ctx.wsb, _stream()), "regt_backward")
+        return (None, None, None, None) + tuple(grads[n_] for n_ in names)
+
+
+def regt_gcn_forward(x, graph: PreparedGraph, params: Dict[str, torch.Tensor], regional: bool = True, slope: float = 0.01):
+    """Functional entry: ``params`` keyed by the reference's state_dict names."""
+    names = param_names(regional)
+    return RegTGCNFunction.apply(x, graph, regional, slope, *[params[n] for n in names])

@@ -1,0 +1,208 @@
+"""Prepared (normalised, destination-sorted) graph operators for the RegT-GCN hot path.
+
+The reference builds its conv layers with ``cached=False`` (models/RegionalTemporalGCN.py:54,73)
+so PyG re-derives 5 Laplacians + 3 GCN normalisations in every period of every forward; the graph
+is static, so here that work happens once, on the GPU (csrc/graph.hip), and is cached.
+
+A :class:`PreparedGraph` holds the stacked CSR the pipeline consumes:
+rows ``[0, N)``  -> ``A_hat = D^-1/2 (A+I) D^-1/2`` of the full graph (GCNConv, models/utils.py:169-181),
+rows ``[N, 2N)`` -> the merged regional scaled Laplacians ``L~_r`` (ChebConv K=2,
+RegionalTemporalGCN.py:136-140), which is valid when every node receives regional edges from at
+most one regional graph ("node-disjoint regions", true for the reference's regional decomposition).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+@dataclass
+class PreparedGraph:
+    num_nodes: int
+    num_regions: int
+    rowptr: torch.Tensor        # (2N+1,) int32
+    col: torch.Tensor           # (nnz,) int32
+    val: torch.Tensor           # (nnz,) float32
+    node_region: torch.Tensor   # (N,) int32
+    node_region_host: np.ndarray
+    nnz_gcn: int
+    nnz_cheb: int
+    _chunks: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = field(default_factory=dict)
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def chunks_for(self, periods: int):
+        """(chunk_tab (n,2) int32, chunk_region (n,) int32, n): row ranges of (node*T+t) rows inside one region."""
+        if periods not in self._chunks:
+            tab, reg = region_chunks(self.node_region_host, periods)
+            self._chunks[periods] = (torch.from_numpy(tab).to(self.device), torch.from_numpy(reg).to(self.device), len(reg))
+        return self._chunks[periods]
+
+
+def region_chunks(node_region: np.ndarray, periods: int):
+    """Split the (node*T + t) row space into chunks that never straddle a region boundary."""
+    n = len(node_region)
+    m = n * periods
+    kc = max(512, ((m + 255) // 256 + 31) // 32 * 32)
+    change = np.flatnonzero(np.diff(node_region)) + 1
+    starts = np.concatenate([[0], change]).astype(np.int64)
+    ends = np.concatenate([change, [n]]).astype(np.int64)
+    tab, reg = [], []
+    for s, e in zip(starts, ends):
+        r0, r1 = s * periods, e * periods
+        while r0 < r1:
+            r2 = min(r0 + kc, r1)
+            tab.append((r0, r2))
+            reg.append(node_region[s])
+            r0 = r2
+    return np.asarray(tab, dtype=np.int32).reshape(-1, 2), np.asarray(reg, dtype=np.int32)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check_edges(edge_index: torch.Tensor, weight: Optional[torch.Tensor], what: str):
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+        raise ValueError(f"{what}: edge_index must be a (2,E) int64 tensor, got {tuple(edge_index.shape)} {edge_index.dtype}")
+    if not edge_index.is_cuda:
+        raise _lib.RegtError(f"{what}: edge_index must live on the GPU (no CPU path)")
+    if weight is not None:
+        if weight.dtype != torch.float32 or weight.numel() != edge_index.shape[1] or weight.device != edge_index.device:
+            raise ValueError(f"{what}: edge weights must be float32 (E,) on the same device")
+
+
+def _raise_flags(flags: torch.Tensor, what: str):
+    f = int(flags.item())
+    if f & 1:
+        raise ValueError(f"{what}: edge_index contains node ids outside [0, num_nodes)")
+    if f & 2:
+        raise ValueError(f"{what}: negative edge weights are not supported (degree^-1/2 normalisation)")
+
+
+def gcn_csr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int):
+    """A_hat as (rowptr, col, val) -- GCNConv's gcn_norm, computed once."""
+    lib = _lib.load()
+    _check_edges(edge_index, edge_weight, "gcn_csr")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    ew = None if edge_weight is None else edge_weight.contiguous()
+    e = ei.shape[1]
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(e + num_nodes, dtype=torch.int32, device=dev)
+    val = torch.empty(e + num_nodes, dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.regt_graph_workspace_bytes(e, num_nodes)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.regt_gcn_csr(_lib.ptr(ei), _lib.ptr(ew), e, num_nodes, _lib.ptr(rowptr), _lib.ptr(col),
+                                _lib.ptr(val), _lib.ptr(flags), _lib.ptr(ws), wsb, _stream()), "regt_gcn_csr")
+    _raise_flags(flags, "gcn_csr")
+    nnz = int(rowptr[-1].item())
+    return rowptr, col[:nnz], val[:nnz]
+
+
+def cheb_edge_weights(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> torch.Tensor:
+    """Per-edge scaled-Laplacian weights (ChebConv.__norm__ with lambda_max=None), computed once."""
+    lib = _lib.load()
+    _check_edges(edge_index, edge_weight, "cheb_edge_weights")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    ew = None if edge_weight is None else edge_weight.contiguous()
+    e = ei.shape[1]
+    out = torch.empty(e, dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.regt_graph_workspace_bytes(e, num_nodes)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.regt_cheb_edge_weights(_lib.ptr(ei), _lib.ptr(ew), e, num_nodes, _lib.ptr(out), _lib.ptr(flags),
+                                          _lib.ptr(ws), wsb, _stream()), "regt_cheb_edge_weights")
+    _raise_flags(flags, "cheb_edge_weights")
+    return out
+
+
+def raw_csr(edge_index: torch.Tensor, edge_value: torch.Tensor, num_nodes: int):
+    lib = _lib.load()
+    _check_edges(edge_index, edge_value, "raw_csr")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.regt_graph_workspace_bytes(e, num_nodes)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.regt_raw_csr(_lib.ptr(ei), _lib.ptr(edge_value.contiguous()), e, num_nodes, _lib.ptr(rowptr),
+                                _lib.ptr(col), _lib.ptr(val), _lib.ptr(flags), _lib.ptr(ws), wsb, _stream()), "regt_raw_csr")
+    _raise_flags(flags, "raw_csr")
+    nnz = int(rowptr[-1].item())
+    return rowptr, col[:nnz], val[:nnz]
+
+
+def fingerprint(tensors: Sequence[Optional[torch.Tensor]]) -> int:
+    """Content hash of a list of (edge_index, weight) style tensors -- one device pass + one 8-byte readback."""
+    lib = _lib.load()
+    total = 0
+    it = iter(tensors)
+    for ei in it:
+        w = next(it)
+        out = torch.zeros(1, dtype=torch.int64, device=ei.device)
+        _lib.check(lib.regt_graph_fingerprint(_lib.ptr(ei.contiguous()), _lib.ptr(None if w is None else w.contiguous()),
+                                              ei.shape[1], _lib.ptr(out), _stream()), "regt_graph_fingerprint")
+        total = (total * 1000003 + (int(out.item()) & 0xFFFFFFFFFFFFFFFF) + ei.shape[1]) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
+def node_regions(region_index: Sequence[torch.Tensor], num_nodes: int) -> np.ndarray:
+    """Region that owns each node's Laplacian row; raises if a node receives edges in two regional graphs."""
+    owner = np.full(num_nodes, -1, dtype=np.int32)
+    for r, ei in enumerate(region_index):
+        e = ei.detach().cpu().numpy()
+        dst = np.unique(e[1][e[0] != e[1]])
+        clash = owner[dst] >= 0
+        if clash.any():
+            raise NotImplementedError(
+                "regional graphs overlap: node %d receives edges in regions %d and %d. The fused path needs "
+                "node-disjoint regional graphs (the reference's 'regional' decomposition); overlapping "
+                "('random') decompositions are not implemented yet." % (int(dst[clash][0]), int(owner[dst[clash][0]]), r))
+        owner[dst] = r
+    # nodes without regional in-edges have an all-zero Laplacian row: attach them to the previous
+    # node's region so that region runs (and wgrad chunks) stay long.
+    last = 0
+    for i in range(num_nodes):
+        if owner[i] < 0:
+            owner[i] = last
+        else:
+            last = owner[i]
+    return owner
+
+
+def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], region_index: Sequence[torch.Tensor],
+                  region_weight: Sequence[Optional[torch.Tensor]], num_nodes: int) -> PreparedGraph:
+    """Build the stacked [A_hat; L~] operator.
+
+    ``gcn_weight`` is None for RegT-GCN (the cell is called with edge_weight=None,
+    RegionalTemporalGCN.py:146-148) and the distance weights for TemporalGCN (TemporalGCN.py:89-90).
+    """
+    if len(region_index) != len(region_weight) or len(region_index) == 0:
+        raise ValueError("need one weight tensor (or None) per regional edge_index")
+    rp_a, col_a, val_a = gcn_csr(edge_index, gcn_weight, num_nodes)
+    w_all = [cheb_edge_weights(ei, ew, num_nodes) for ei, ew in zip(region_index, region_weight)]
+    owner = node_regions(region_index, num_nodes)
+    ei_all = torch.cat([ei for ei in region_index], dim=1)
+    rp_l, col_l, val_l = raw_csr(ei_all, torch.cat(w_all), num_nodes)
+    nnz_a = int(col_a.numel())
+    rowptr = torch.cat([rp_a, rp_l[1:] + nnz_a]).contiguous()
+    col = torch.cat([col_a, col_l]).contiguous()
+    val = torch.cat([val_a, val_l]).contiguous()
+    if col.numel() == 0:
+        raise ValueError("graph has no edges and no nodes")
+    return PreparedGraph(num_nodes=num_nodes, num_regions=len(region_index), rowptr=rowptr, col=col, val=val,
+                         node_region=torch.from_numpy(owner).to(edge_index.device), node_region_host=owner,
+                         nnz_gcn=nnz_a, nnz_cheb=int(col_l.numel()))

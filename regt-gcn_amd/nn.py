@@ -1,0 +1,228 @@
+"""Drop-in ``nn.Module`` surface of the RegT-GCN hot path.
+
+Same constructor / ``forward()`` signatures, parameter names and ``state_dict`` layout as the
+reference classes, so the reference's ``run.py`` / ``predict.py`` and its shipped checkpoints work
+unchanged:
+
+* :class:`RegionalTemporalGCN`  <-> models/RegionalTemporalGCN.py:9-39  (+ RegionalA3TGCN :42-149)
+* :class:`TemporalGCN`          <-> models/TemporalGCN.py:7-32          (+ A3TGCN :35-91)
+* :class:`TGCN`                 <-> models/utils.py:69-203 (parameter container of the GRU cell)
+
+The modules only *hold* parameters; all arithmetic runs in libregtgcn_hip.so through
+:class:`regt-gcn_amd.functional.RegTGCNFunction`.  There is no CPU implementation here: calling
+``forward`` with CPU tensors raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .functional import HEAD_HIDDEN, RegTGCNFunction, param_names
+from .graph import PreparedGraph, fingerprint, prepare_graph
+
+HIDDEN = 256          # out_channels=256, models/RegionalTemporalGCN.py:14 / models/TemporalGCN.py:12
+LEAKY_SLOPE = 0.01    # F.leaky_relu default, models/RegionalTemporalGCN.py:143
+
+
+class _PygLinear(nn.Module):
+    """Bias-free linear parameter holder named like torch_geometric's Linear (``.weight`` (out,in), glorot)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        a = math.sqrt(6.0 / (in_channels + out_channels))
+        nn.init.uniform_(self.weight, -a, a)
+
+
+class _GCNConvParams(nn.Module):
+    """Parameters of a PyG GCNConv: ``bias`` (C,) zero-init and ``lin.weight`` (C,F)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.lin = _PygLinear(in_channels, out_channels)
+
+
+class _ChebConvParams(nn.Module):
+    """Parameters of a PyG ChebConv(K=2): ``bias`` and ``lins.{0,1}.weight``."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.lins = nn.ModuleList([_PygLinear(in_channels, out_channels) for _ in range(2)])
+
+
+class TGCN(nn.Module):
+    """Parameter layout of the reference's T-GCN GRU cell (models/utils.py:75-161, baseblock 'gcn')."""
+
+    def __init__(self, in_channels: int, out_channels: int, baseblock: str = "gcn", improved: bool = False,
+                 cached: bool = False, add_self_loops: bool = True):
+        super().__init__()
+        if baseblock != "gcn" or improved or not add_self_loops:
+            raise NotImplementedError("only baseblock='gcn', improved=False, add_self_loops=True is on the hot path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.conv_z = _GCNConvParams(in_channels, out_channels)
+        self.linear_z = nn.Linear(2 * out_channels, out_channels)
+        self.conv_r = _GCNConvParams(in_channels, out_channels)
+        self.linear_r = nn.Linear(2 * out_channels, out_channels)
+        self.conv_h = _GCNConvParams(in_channels, out_channels)
+        self.linear_h = nn.Linear(2 * out_channels, out_channels)
+
+
+class _GraphCache:
+    """Prepared graphs keyed first by tensor identity (free), then by content fingerprint (one 8-byte readback)."""
+
+    def __init__(self):
+        self._by_id: Dict[tuple, PreparedGraph] = {}
+        self._by_hash: Dict[tuple, PreparedGraph] = {}
+
+    @staticmethod
+    def _ident(tensors):
+        return tuple((t.data_ptr(), tuple(t.shape), t._version) if t is not None else None for t in tensors)
+
+    def get(self, tensors: Sequence[Optional[torch.Tensor]], num_nodes: int, build):
+        key = (num_nodes,) + self._ident(tensors)
+        g = self._by_id.get(key)
+        if g is not None:
+            return g
+        hkey = (num_nodes, fingerprint(tensors))
+        g = self._by_hash.get(hkey)
+        if g is None:
+            g = build()
+            self._by_hash[hkey] = g
+        if len(self._by_id) > 64:
+            self._by_id.clear()
+        self._by_id[key] = g
+        return g
+
+
+def _need_cuda(x: torch.Tensor):
+    if not x.is_cuda:
+        raise _lib.RegtError("this package only runs on an MI355X through libregtgcn_hip.so; got a CPU tensor "
+                             "(use oracle/ for CPU checks)")
+
+
+class RegionalA3TGCN(nn.Module):
+    """Parameter layout of models/RegionalTemporalGCN.py:42-88 (attention over periods + regional ChebConv + TGCN)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, periods: int, improved: bool = False,
+                 cached: bool = False, add_self_loops: bool = True, num_regions: int = 5):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_nodes, self.periods, self.num_regions = num_nodes, periods, num_regions
+        self._attention = nn.Parameter(torch.empty(periods))
+        # registered-but-unused parameters of the reference's dead attention() (:84-87, :91-111)
+        self._weight_att1 = nn.Parameter(torch.normal(0.0, 0.1, size=(out_channels, 1)))
+        self._weight_att2 = nn.Parameter(torch.normal(0.0, 0.1, size=(num_nodes, 1)))
+        self._bias_att1 = nn.Parameter(torch.normal(0.0, 1.0, size=(1, 1)))
+        self._bias_att2 = nn.Parameter(torch.normal(0.0, 1.0, size=(1, 1)))
+        self._base_tgcn = TGCN(in_channels, out_channels, improved=improved, cached=cached, add_self_loops=add_self_loops)
+        self.conv = _ChebConvParams(in_channels, out_channels)
+        self.linear = nn.Linear(out_channels * num_regions, out_channels)
+        nn.init.uniform_(self._attention)
+
+
+class A3TGCN(nn.Module):
+    """Parameter layout of models/TemporalGCN.py:35-73 (incl. its dead ``linear`` (64 -> C), :70)."""
+
+    def __init__(self, in_channels: int, out_channels: int, periods: int, improved: bool = False, cached: bool = False,
+                 add_self_loops: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.periods = in_channels, out_channels, periods
+        self._base_tgcn = TGCN(in_channels, out_channels)
+        self.conv = _ChebConvParams(in_channels, out_channels)
+        self.linear = nn.Linear(64, out_channels)
+        self._attention = nn.Parameter(torch.empty(periods))
+        nn.init.uniform_(self._attention)
+
+
+class _FusedModel(nn.Module):
+    regional: bool
+
+    def _params_in_order(self) -> List[torch.Tensor]:
+        named = dict(self.named_parameters())
+        return [named[n] for n in param_names(self.regional)]
+
+    def _run(self, x: torch.Tensor, graph: PreparedGraph):
+        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, *self._params_in_order())
+
+
+class RegionalTemporalGCN(_FusedModel):
+    """RegT-GCN.  ``forward`` keeps the reference's 12-positional-argument form (5 named regions,
+    models/RegionalTemporalGCN.py:25-26) and also accepts any number R of regions as
+    ``forward(x, edge_index, idx_1..idx_R, attr_1..attr_R)`` or ``forward(x, edge_index, [idx...], [attr...])``.
+    Returns ``(prediction (N, output_dim), hidden (N, 256))``."""
+
+    regional = True
+
+    def __init__(self, node_features: int, num_nodes: int, periods: int, output_dim: int, num_regions: int = 5,
+                 hidden_channels: int = HIDDEN):
+        super().__init__()
+        self.tgnn = RegionalA3TGCN(in_channels=node_features, out_channels=hidden_channels, num_nodes=num_nodes,
+                                   periods=periods, num_regions=num_regions)
+        self.output_dim = output_dim
+        self.linear1 = nn.Linear(hidden_channels, HEAD_HIDDEN)
+        self.linear2 = nn.Linear(HEAD_HIDDEN, output_dim)
+        self.relu = nn.ReLU()
+        self.num_nodes, self.num_regions = num_nodes, num_regions
+        self._graphs = _GraphCache()
+
+    def prepare_graph(self, edge_index, region_index: Sequence[torch.Tensor], region_attr: Sequence[torch.Tensor],
+                      num_nodes: Optional[int] = None) -> PreparedGraph:
+        """Normalise + sort the static graph once; pass the result to :meth:`forward_prepared`."""
+        n = self.num_nodes if num_nodes is None else num_nodes
+        return prepare_graph(edge_index, None, list(region_index), list(region_attr), n)
+
+    def forward_prepared(self, x: torch.Tensor, graph: PreparedGraph):
+        _need_cuda(x)
+        return self._run(x, graph)
+
+    def forward(self, x, edge_index, *regions):
+        _need_cuda(x)
+        if len(regions) == 2 and isinstance(regions[0], (list, tuple)):
+            idx, attr = list(regions[0]), list(regions[1])
+        else:
+            if len(regions) != 2 * self.num_regions:
+                raise TypeError(f"forward() expects {self.num_regions} regional edge_index tensors followed by "
+                                f"{self.num_regions} edge_attr tensors, got {len(regions)} tensors")
+            idx, attr = list(regions[:self.num_regions]), list(regions[self.num_regions:])
+        if len(idx) != self.num_regions:
+            raise TypeError(f"model was built for {self.num_regions} regions, got {len(idx)}")
+        n = x.shape[0]
+        flat: List[Optional[torch.Tensor]] = [edge_index, None]
+        for i, a in zip(idx, attr):
+            flat += [i, a]
+        graph = self._graphs.get(flat, n, lambda: prepare_graph(edge_index, None, idx, attr, n))
+        return self._run(x, graph)
+
+
+class TemporalGCN(_FusedModel):
+    """A3T-GCN baseline sharing the cell.  ``forward(x, edge_index, edge_attr)`` (models/TemporalGCN.py:21)."""
+
+    regional = False
+
+    def __init__(self, node_features: int, periods: int, output_dim: int, hidden_channels: int = HIDDEN):
+        super().__init__()
+        self.tgnn = A3TGCN(in_channels=node_features, out_channels=hidden_channels, periods=periods)
+        self.output_dim = output_dim
+        self.linear1 = nn.Linear(hidden_channels, HEAD_HIDDEN)
+        self.linear2 = nn.Linear(HEAD_HIDDEN, output_dim)
+        self.relu = nn.ReLU()
+        self._graphs = _GraphCache()
+
+    def prepare_graph(self, edge_index, edge_attr, num_nodes: int) -> PreparedGraph:
+        return prepare_graph(edge_index, edge_attr, [edge_index], [edge_attr], num_nodes)
+
+    def forward_prepared(self, x: torch.Tensor, graph: PreparedGraph):
+        _need_cuda(x)
+        return self._run(x, graph)
+
+    def forward(self, x, edge_index, edge_attr):
+        _need_cuda(x)
+        n = x.shape[0]
+        graph = self._graphs.get([edge_index, edge_attr], n, lambda: prepare_graph(edge_index, edge_attr, [edge_index], [edge_attr], n))
+        return self._run(x, graph)

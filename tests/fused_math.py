@@ -1,0 +1,70 @@
+"""Torch statement of the *fused formulation* the HIP pipeline implements.
+
+Test helper only: it mirrors, stage by stage and with hand-derived backward formulas, what the
+HIP kernels compute, so a failing GPU parity test can be bisected per stage.  It is checked
+against the oracle in tests/test_fused_math.py (CPU) -- that test is what validates the algebra
+(aggregate-first, composed weights, no sparse backward).
+"""
+from __future__ import annotations
+
+import torch
+
+from oracle import graph_ops as G
+
+LRELU = 0.01
+
+
+def dense_ops(edge_index, edge_weight, region_index, region_weight, n, dtype):
+    """A_hat (N,N) and the list of L~_r (N,N) as dense matrices."""
+    src, dst, w = G.gcn_norm_edges(edge_index, edge_weight, n, dtype)
+    a = torch.zeros(n, n, dtype=dtype).index_put_((dst, src), w, accumulate=True)
+    ls = []
+    for ei, ew in zip(region_index, region_weight):
+        s, d, wl = G.cheb_norm_edges(ei, ew, n, dtype)
+        ls.append(torch.zeros(n, n, dtype=dtype).index_put_((d, s), wl, accumulate=True))
+    return a, ls
+
+
+def compose(p, num_regions, regional=True, prefix="tgnn."):
+    """Composed weights: everything that multiplies an input of width F is folded to (C,F)."""
+    C = p[f"{prefix}conv.bias"].numel()
+    w0, w1, bc = p[f"{prefix}conv.lins.0.weight"], p[f"{prefix}conv.lins.1.weight"], p[f"{prefix}conv.bias"]
+    out = {}
+    if regional:
+        wl = p[f"{prefix}linear.weight"]
+        blocks = [wl[:, r * C:(r + 1) * C] for r in range(num_regions)]
+        wsum = sum(blocks)
+        out["A0"] = wsum @ w0
+        out["Ar"] = [b @ w1 for b in blocks]
+        out["b"] = wsum @ bc + p[f"{prefix}linear.bias"]
+    else:
+        out["A0"], out["Ar"], out["b"] = w0, [w1], bc
+    for k in "zrh":
+        u = p[f"{prefix}_base_tgcn.linear_{k}.weight"]
+        u1, u2 = u[:, :C], u[:, C:]
+        out[f"G{k}"] = u1 @ p[f"{prefix}_base_tgcn.conv_{k}.lin.weight"]
+        out[f"c{k}"] = u1 @ p[f"{prefix}_base_tgcn.conv_{k}.bias"] + p[f"{prefix}_base_tgcn.linear_{k}.bias"]
+        out[f"U{k}"] = u2
+    return out
+
+
+def forward_fused(p, x, a_hat, l_list, regional=True):
+    """x (N,F,T).  Returns (pred, hidden) through the composed-weight formulation using autograd."""
+    n, f, t = x.shape
+    R = len(l_list)
+    w = compose(p, R, regional)
+    xp = x.permute(0, 2, 1)                              # (N,T,F) packed rows
+    ax = torch.einsum("ij,jtf->itf", a_hat, xp)
+    pre = xp @ w["A0"].t() + w["b"]
+    for r in range(R):
+        pre = pre + torch.einsum("ij,jtf->itf", l_list[r], xp) @ w["Ar"][r].t()
+    h = torch.nn.functional.leaky_relu(pre, LRELU) if regional else pre
+    z = torch.sigmoid(h @ w["Uz"].t() + ax @ w["Gz"].t() + w["cz"])
+    r_ = torch.sigmoid(h @ w["Ur"].t() + ax @ w["Gr"].t() + w["cr"])
+    ht = torch.tanh((h * r_) @ w["Uh"].t() + ax @ w["Gh"].t() + w["ch"])
+    hn = z * h + (1 - z) * ht
+    probs = torch.softmax(p["tgnn._attention"], dim=0)
+    hidden = (hn * probs.view(1, t, 1)).sum(dim=1)
+    y = torch.relu(hidden) @ p["linear1.weight"].t() + p["linear1.bias"]
+    y = torch.relu(y) @ p["linear2.weight"].t() + p["linear2.bias"]
+    return y, hidden

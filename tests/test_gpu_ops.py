@@ -1,0 +1,170 @@
+"""GPU parity of the op-site kernels (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import region_lists
+from oracle import graph_ops as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    import regtgcn_amd
+    regtgcn_amd.load_library()
+    return regtgcn_amd
+
+
+def _csr_to_dense(rowptr, col, val, n):
+    rowptr, col, val = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy().astype(np.float64)
+    d = np.zeros((len(rowptr) - 1, n), dtype=np.float64)
+    for i in range(len(rowptr) - 1):
+        for p in range(rowptr[i], rowptr[i + 1]):
+            d[i, col[p]] += val[p]
+    return d
+
+
+def _rand_graph(n, e, seed, loops=True):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    if loops and e > 4:
+        src[0] = dst[0] = 1
+        src[1] = dst[1] = 1           # two self loops on node 1: the last listed weight wins
+        src[2], dst[2] = src[3], dst[3]   # duplicate edge
+    w = torch.rand(e, generator=g) * 100 + 1
+    return torch.stack([src, dst]), w
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n,e,seed", [(9, 25, 0), (104, 400, 1), (1000, 12000, 2), (5, 0, 3)])
+def test_gcn_csr_matches_oracle(R, n, e, seed, weighted):
+    ei, w = _rand_graph(n, e, seed)
+    ew = w if weighted else None
+    rp, col, val = R.graph.gcn_csr(ei.cuda(), None if ew is None else ew.cuda(), n)
+    got = _csr_to_dense(rp, col, val, n)
+    want = G.dense_gcn_operator(ei, ew, n, torch.float64).numpy()
+    np.testing.assert_allclose(got, want, atol=2e-7, rtol=1e-6)
+    # bit-exact against the fp32 edge-ordered restatement (same op order)
+    s, d, wn = G.gcn_norm_edges(ei, ew, n, torch.float32)
+    ref = np.zeros((n, n), dtype=np.float64)
+    np.add.at(ref, (d.numpy(), s.numpy()), wn.numpy().astype(np.float64))
+    np.testing.assert_allclose(got, ref, atol=0, rtol=2e-7)
+    # rows are sorted by destination and keep edge order: deterministic rebuild
+    rp2, col2, val2 = R.graph.gcn_csr(ei.cuda(), None if ew is None else ew.cuda(), n)
+    assert torch.equal(rp, rp2) and torch.equal(col, col2) and torch.equal(val, val2)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("n,e,seed", [(9, 25, 0), (104, 400, 1), (1000, 12000, 2)])
+def test_cheb_operator_matches_oracle(R, n, e, seed, weighted):
+    ei, w = _rand_graph(n, e, seed)
+    ew = w if weighted else None
+    wt = R.graph.cheb_edge_weights(ei.cuda(), None if ew is None else ew.cuda(), n)
+    rp, col, val = R.graph.raw_csr(ei.cuda(), wt, n)
+    got = _csr_to_dense(rp, col, val, n)
+    want = G.dense_cheb_operator(ei, ew, n, torch.float64).numpy()
+    np.testing.assert_allclose(got, want, atol=2e-7, rtol=1e-6)
+    assert np.all(np.diag(got) == 0)
+
+
+def test_graph_rejects_bad_indices(R):
+    ei = torch.tensor([[0, 7], [1, 2]]).cuda()
+    with pytest.raises(ValueError):
+        R.graph.gcn_csr(ei, None, 5)
+    with pytest.raises(ValueError):
+        R.graph.cheb_edge_weights(torch.tensor([[0, 1], [1, 0]]).cuda(), torch.tensor([1.0, -2.0]).cuda(), 3)
+
+
+@pytest.mark.parametrize("width", [4, 32, 48, 96, 128, 256, 384, 768, 1024])
+def test_spmm_matches_oracle(R, width):
+    n, e = 777, 9000
+    ei, w = _rand_graph(n, e, 5)
+    rp, col, val = R.graph.gcn_csr(ei.cuda(), w.cuda(), n)
+    x = torch.randn(n, width)
+    got = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
+    s, d, wn = G.gcn_norm_edges(ei, w, n, torch.float32)
+    want = G.propagate(s, d, wn, x, n)
+    assert float((got - want).abs().max()) < 2e-6
+    want64 = G.dense_gcn_operator(ei, w, n, torch.float64) @ x.double()
+    assert float((got.double() - want64).abs().max()) < 5e-6
+
+
+def test_spmm_empty_rows_and_hub(R):
+    # node 0 receives every edge (hub), nodes 5.. receive none
+    n = 300
+    src = torch.arange(1, n)
+    ei = torch.stack([src, torch.zeros_like(src)])
+    wt = torch.rand(n - 1) + 0.5
+    rp, col, val = R.graph.raw_csr(ei.cuda(), wt.cuda(), n)
+    x = torch.randn(n, 96)
+    got = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
+    want = torch.zeros(n, 96)
+    want[0] = (wt.double().view(-1, 1) * x[1:].double()).sum(0).float()
+    assert float((got - want).abs().max()) < 1e-4      # 299-term fp32 sum in edge order
+    assert float(got[1:].abs().max()) == 0.0
+
+
+def test_pack_x(R):
+    x = torch.randn(37, 8, 12)
+    assert torch.equal(R.ops.pack_x(x.cuda()).cpu(), x.permute(0, 2, 1).contiguous())
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 1, 1), (104, 8, 256), (624, 256, 512), (1000, 36, 130), (129, 257, 65), (4096, 256, 256)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_matches_torch_fp32(R, m, k, n, act):
+    g = torch.Generator().manual_seed(m * 31 + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / max(1.0, k ** 0.5)
+    b = torch.randn(n, generator=g)
+    got = R.ops.linear(a.cuda(), w.cuda(), b.cuda(), act).cpu()
+    want = a.double() @ w.double().t() + b.double()
+    if act == 1:
+        want = torch.nn.functional.leaky_relu(want, 0.01)
+    elif act == 2:
+        want = torch.relu(want)
+    # fp32 MFMA = k-ordered fp32 fma chain: error ~ 1e-7 * sum|a*w|
+    assert float((got.double() - want).abs().max()) < 2e-5
+
+
+def test_linear_asymmetric_identity(R):
+    # A = I with an asymmetric weight catches a transposed C write (cdna guide section 3)
+    k = 64
+    w = torch.arange(96 * k, dtype=torch.float32).reshape(96, k) / 100.0
+    got = R.ops.linear(torch.eye(k).cuda(), w.cuda()).cpu()
+    assert torch.equal(got, w.t().contiguous())
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (624, 256, 256), (5000, 512, 256), (3000, 256, 8), (700, 128, 33), (40000, 256, 32)])
+def test_wgrad_matches_torch(R, m, n, k):
+    g = torch.Generator().manual_seed(m + n + k)
+    d = torch.randn(m, n, generator=g)
+    a = torch.randn(m, k, generator=g)
+    dw, db = R.ops.wgrad(d.cuda(), a.cuda())
+    want = d.double().t() @ a.double()
+    scale = max(1.0, m ** 0.5)
+    assert float((dw.cpu().double() - want).abs().max()) < 3e-5 * scale
+    assert float((db.cpu().double() - d.double().sum(0)).abs().max()) < 3e-5 * scale
+    dw2, db2 = R.ops.wgrad(d.cuda(), a.cuda())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)   # slab reduction is deterministic
+
+
+def test_prepared_graph_tpims(R, tpims):
+    ri, rw = region_lists(tpims)
+    n = tpims["node_data"].shape[0]
+    g = R.prepare_graph(tpims["edge_index"].cuda(), None, [t.cuda() for t in ri], [t.cuda() for t in rw], n)
+    d = _csr_to_dense(g.rowptr, g.col, g.val, n)
+    np.testing.assert_allclose(d[:n], G.dense_gcn_operator(tpims["edge_index"], None, n).numpy(), atol=2e-7)
+    lsum = sum(G.dense_cheb_operator(i, w, n).numpy() for i, w in zip(ri, rw))
+    np.testing.assert_allclose(d[n:], lsum, atol=2e-7)
+    bounds = [0, 44, 62, 75, 93, 104]
+    for r in range(5):
+        assert np.all(g.node_region_host[bounds[r]:bounds[r + 1]] == r)
+
+
+def test_overlapping_regions_rejected(R):
+    a = torch.tensor([[0, 1], [1, 0]]).cuda()
+    b = torch.tensor([[2, 1], [1, 2]]).cuda()      # node 1 also receives an edge in region b
+    with pytest.raises(NotImplementedError):
+        R.prepare_graph(a, None, [a, b], [None, None], 3)
