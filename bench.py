@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the RegT-GCN hot path on MI355X (contract: see the task README / DESIGN.md section 6).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "cfg-3"): synthetic regional graph, 100 000 nodes / 1 000 000
+directed edges / 8 regions / 32 node features / T = 12 periods / horizon 1, fp32, per GPU.
+A "step" is what the reference's run.py::train() does per snapshot: forward, mean((out-y)^2),
+backward with gradients accumulating (run.py:178-191); the optimiser (RMSprop, run.py:145) steps once
+per epoch, here once at the end of the K timed steps, inside the timed region.
+
+N > 1: weak scaling, region-sharded.  The global graph has N*100k nodes and N*8 regions; rank g owns
+8 regions, all-gathers the packed boundary rows over RCCL every step and all-reduces the gradient
+buffer once before the optimiser step.  ``value`` counts 100k-node shard snapshots per second over all
+ranks (= N * steps / time).
+
+The JSON line carries ``roofline`` (dominant kernel, measured with HIP events recorded on the launch
+stream by the library itself: regt_profile_*) and ``cpu_baseline`` (the oracle's eager-faithful CPU
+path timed on the host cores of this box, rank 0, N = 1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs, 2.4 GHz
+PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s is the measured achievable copy rate)
+
+WORKLOADS = {
+    # name: (nodes, edges, regions, F, T, O) per GPU
+    "cfg3": (100_000, 1_000_000, 8, 32, 12, 1),
+    "small": (20_000, 200_000, 8, 32, 12, 1),       # quick functional run
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(nodes, edges, regions, F, T, O, seed=42):
+    """Oracle (op-for-op restatement of the reference CPU path) on the host cores.
+
+    A full T=12 step at this size needs > 57 GB and ~90 s, so the bounded sample
+    is ONE period (T=1) of the same graph, forward + loss + backward; periods are independent in
+    the reference (RegionalTemporalGCN.py:135-148), so the step time is T x the period time."""
+    import regtgcn_amd as R
+    from oracle import model as M
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)          # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe)
+    torch.set_num_threads(cores)
+    g = R.data.synthetic_regional_graph(nodes, edges, regions, seed=seed)
+    (x, y), = R.data.synthetic_snapshots(nodes, F, 1, O, 1, seed=seed)
+    p = M.init_params("RegionalTemporalGCN", F, 1, O, num_nodes=nodes, num_regions=regions, seed=seed)
+    p = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    t0 = time.perf_counter()
+    pred, _ = M.regional_temporal_gcn(p, x, g.edge_index, g.region_index, g.region_attr)
+    loss = torch.mean((pred - y) ** 2)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / (dt * T), "unit": "snapshots/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {T} periods (T=1 forward+loss+backward, {dt:.2f} s) of the same {nodes}-node/{edges}-edge/"
+                      f"{regions}-region graph; periods are independent, step time = {T} x period time"}
+
+
+def stage_flops(stage, M, C, F):
+    return {
+        "gemm_gates": 2.0 * M * 2 * C * (C + F), "gemm_candidate": 2.0 * M * C * (C + F),
+        "gemm_regional": 2.0 * M * C * 2 * F, "dgrad_candidate": 2.0 * M * C * C, "dgrad_gates": 2.0 * M * C * 2 * C,
+        "wgrad_Uh": 2.0 * M * C * C, "wgrad_Uzr": 2.0 * M * 2 * C * C, "wgrad_Gh": 2.0 * M * C * F,
+        "wgrad_Gzr": 2.0 * M * 2 * C * F, "wgrad_A0": 2.0 * M * C * F, "wgrad_Ar": 2.0 * M * C * F,
+    }.get(stage)
+
+
+def main():
+    args = parse()
+    nodes, edges, regions, F, T, O = WORKLOADS[args.workload]
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(nodes, edges, regions, F, T, O)))
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import regtgcn_amd as R
+    from regtgcn_amd import _lib
+    lib = R.load_library()
+
+    # ---- data: global graph of world*cfg shape, this rank's shard ------------------------------------
+    gnodes, gedges, gregions = nodes * world, edges * world, regions * world
+    g = R.data.synthetic_regional_graph(gnodes, gedges, gregions, seed=42)
+    C = R.nn.HIDDEN
+    torch.manual_seed(42)                     # same random-init weights on every rank (run.py:71)
+    model = R.RegionalTemporalGCN(node_features=F, num_nodes=nodes, periods=T, output_dim=O, num_regions=regions)
+    model = model.to(dev)
+    n_snap = 4
+    snaps = R.data.synthetic_snapshots(gnodes, F, T, O, n_snap, seed=42)
+    lo, hi = rank * nodes, (rank + 1) * nodes
+    xs = [x[lo:hi].contiguous().to(dev) for x, _ in snaps]
+    ys = [y[lo:hi].contiguous().to(dev) for _, y in snaps]
+    if world == 1:
+        graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index],
+                                [t.to(dev) for t in g.region_attr], nodes)
+        shard = None
+    else:
+        owner_bounds = np.arange(world + 1, dtype=np.int64) * nodes
+        region_owner = [r // regions for r in range(gregions)]
+        shard = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, gnodes, owner_bounds, region_owner,
+                                   rank, world, dev)
+        graph = shard.graph
+        xp_ext = torch.empty(shard.topo.x_rows, T, F, dtype=torch.float32, device=dev)
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)   # run.py:145
+    params = list(model.parameters())
+    inv_count = 1.0 / float(gnodes * O)
+
+    def step(i):
+        x, y = xs[i % n_snap], ys[i % n_snap]
+        if shard is None:
+            pred, _ = model.forward_prepared(x, graph)
+        else:
+            _lib.check(lib.regt_pack_x(_lib.ptr(x), _lib.ptr(xp_ext), nodes, F, T, torch.cuda.current_stream().cuda_stream), "regt_pack_x")
+            R.dist.exchange_boundary_rows(xp_ext.view(shard.topo.x_rows, T * F), shard.topo, shard.send_idx)
+            pred, _ = model.forward_packed(xp_ext, graph)
+        loss = ((pred - y) ** 2).sum() * inv_count        # mean over the GLOBAL graph (run.py:180)
+        loss.backward()
+        return loss
+
+    def epoch_end():
+        R.dist.allreduce_gradients(params)
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if args.warmup:
+        epoch_end()
+    fence()
+    profile = not args.no_profile
+    if profile:
+        lib.regt_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    epoch_end()
+    fence()
+    dt = time.perf_counter() - t0
+    stages = {}
+    if profile:
+        lib.regt_profile_enable(0)
+        buf = (__import__("ctypes").c_char * 16384)()
+        _lib.check(lib.regt_profile_collect(buf, 16384), "regt_profile_collect")
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            stages[name] = (int(cnt), float(ms))
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final_loss = float(loss.detach())
+
+    if rank == 0:
+        M = nodes * T
+        out = {
+            "metric": "training steps/sec (graph-snapshots/sec)", "value": world * args.steps / dt, "unit": "snapshots/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: synthetic regional graph, {nodes} nodes / {edges} edges / {regions} regions "
+                                   f"per GPU, F={F}, T={T}, O={O}, hidden=256; RegionalTemporalGCN forward+MSE+backward per "
+                                   "snapshot, RMSprop step once per K steps (run.py semantics)",
+                       "global_nodes": gnodes, "global_edges": gedges, "global_regions": gregions,
+                       "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: boundary-row all-gather/step + 1 grad all-reduce",
+                       "final_loss": final_loss},
+        }
+        if stages:
+            per = {k: {"launches": c, "avg_ms": ms / c} for k, (c, ms) in stages.items()}
+            mfma = [(ms, k) for k, (c, ms) in stages.items() if stage_flops(k, M, C, F)]
+            tot_ms, dom = max(mfma)
+            cnt = stages[dom][0]
+            avg_s = tot_ms / cnt * 1e-3
+            achieved = stage_flops(dom, M, C, F) / avg_s / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                               "avg_ms": avg_s * 1e3, "flops_per_launch": stage_flops(dom, M, C, F)}
+            if "spmm" in stages:
+                c, ms = stages["spmm"]
+                W = T * F
+                nnz = int(graph.col.numel())
+                x_rows = nodes if shard is None else shard.topo.x_rows
+                algo = x_rows * W * 4 + nnz * 8 + (2 * nodes + 1) * 4 + 2 * nodes * W * 4
+                gbs = algo / (ms / c * 1e-3) / 1e9
+                out["roofline_spmm"] = {"kernel": "spmm_csr (stacked [A_hat; L~] x, width T*F)", "bound": "hbm", "achieved": gbs,
+                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                        "avg_ms": ms / c, "bytes_per_launch": algo}
+            gemm_ms = sum(ms for k, (c, ms) in stages.items() if stage_flops(k, M, C, F))
+            gemm_fl = sum(stage_flops(k, M, C, F) * c for k, (c, ms) in stages.items() if stage_flops(k, M, C, F))
+            out["mfma_all_gemms"] = {"achieved": gemm_fl / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                                     "unit": "TFLOP/s", "share_of_step": gemm_ms / (dt * 1e3)}
+            out["stages"] = per
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nodes, edges, regions, F, T, O)
+            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,11 +158,26 @@ size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks);
 int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
                      float* pred, float* hidden, void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* Region-sharded variant (one process per GPU): the caller has already packed its own N rows with
+ * regt_pack_x into the first N rows of x_packed (x_rows >= N rows of T*F floats) and filled rows
+ * [N, x_rows) with the halo rows received from the other ranks; graph->col of the A_hat half may
+ * point at any of the x_rows rows.  Everything else is as regt_forward. */
+int32_t regt_forward_packed(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
+                            const float* x_packed, int32_t x_rows, float* pred, float* hidden,
+                            void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
 /* Gradients of all parameters given dL/dpred (N,O) and optionally dL/dhidden (N,C) (may be NULL).
- * Must follow regt_forward on the same workspace; `hidden` is that forward's hidden output. */
+ * Must follow regt_forward on the same workspace; `hidden` is that forward's hidden output;
+ * x_packed is NULL after regt_forward, or the buffer given to regt_forward_packed. */
 int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
                       const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
-                      void* workspace, size_t workspace_bytes, regt_stream_t stream);
+                      const float* x_packed, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figures).  collect() waits for the recorded events and writes "name count total_ms"
+ * lines into buf. */
+int32_t regt_profile_enable(int32_t on);
+int32_t regt_profile_collect(char* buf, size_t buf_bytes);
 
 /* loss = mean((pred - y)^2) over `count` entries with mean taken over `global_count`
  * (run.py:180); writes dpred = dloss/dpred and the scalar loss. */

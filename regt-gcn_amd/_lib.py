@@ -62,8 +62,12 @@ SIGNATURES = {
     "regt_wgrad": (C.c_int32, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp]),
     "regt_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int32]),
     "regt_forward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_forward_packed": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, C.c_int32, vp, vp, vp,
+                                        C.c_size_t, vp]),
     "regt_backward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), C.POINTER(Grads), vp, vp, vp,
-                                  vp, C.c_size_t, vp]),
+                                  vp, vp, C.c_size_t, vp]),
+    "regt_profile_enable": (C.c_int32, [C.c_int32]),
+    "regt_profile_collect": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "regt_mse_loss_grad": (C.c_int32, [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]),
 }
 

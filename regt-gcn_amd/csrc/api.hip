@@ -11,6 +11,11 @@
 #include <limits.h>
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "../../include/regtgcn.h"
 #include "kernels.h"
 
@@ -23,6 +28,30 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- optional per-kernel timing with HIP events (bench.py roofline) ---------------------------------
+// When enabled, every pipeline stage is bracketed by two events recorded on the launch stream.
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+struct ProfScope {
+    hipStream_t st; bool on; ProfRec r;
+    ProfScope(const char* name, hipStream_t s) : st(s), on(g_prof_on) {
+        if (!on) return;
+        r.name = name;
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(r);
+    }
+};
+#define PROF(name, st) ProfScope _prof_scope_(name, st)
 
 namespace {
 
@@ -157,15 +186,25 @@ int compose_forward(const regt_dims& d, const regt_params& p, const Layout& L, h
     return REGT_OK;
 }
 
-int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, float* pred,
-                 float* hidden, const Layout& L, hipStream_t st) {
+int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, const float* xp_ext,
+                 int x_rows, float* pred, float* hidden, const Layout& L, hipStream_t st) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
     const long M = (long)N * T;
-    TRY(launch_softmax_small(p.attention, L.probs, T, st));
-    TRY(compose_forward(d, p, L, st));
+    {
+        PROF("compose_fwd", st);
+        TRY(launch_softmax_small(p.attention, L.probs, T, st));
+        TRY(compose_forward(d, p, L, st));
+    }
     // 1. pack the snapshot and aggregate: [A_hat; L~] x  (one stacked SpMM over 2N rows, width T*F)
-    TRY(launch_pack_x(x, L.Xp, N, F, T, st));
-    TRY(launch_spmm_csr(g.rowptr, g.col, g.val, L.Xp, L.AX, 2 * N, N, T * F, st));
+    const float* Xp = xp_ext ? xp_ext : L.Xp;
+    if (!xp_ext) {
+        PROF("pack_x", st);
+        TRY(launch_pack_x(x, L.Xp, N, F, T, st));
+    }
+    {
+        PROF("spmm", st);
+        TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, st));
+    }
     const float* A0 = d.regional ? L.A0 : p.cheb_w0;
     const float* Aall = d.regional ? L.Aall : p.cheb_w1;
     const float* bpr = d.regional ? L.bprime : p.cheb_bias;
@@ -173,11 +212,12 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(L.Xp, F, A0, nullptr, F, INT_MAX, F, true);
+        S.seg[0] = make_seg(Xp, F, A0, nullptr, F, INT_MAX, F, true);
         S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true, R > 1 ? SEG_REGION : 0, (long)C * F);
         S.node_region = g.node_region;
         S.row_div = T;
         EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        PROF("gemm_regional", st);
         TRY(launch_gemm_bias_act(S, M, C, e, st));
     }
     // 3. update + reset gates: [Z|R] = sigmoid(h [Uz2;Ur2]^T + (A_hat x) [Gz;Gr]^T + [cz;cr]),  q = h*R
@@ -188,6 +228,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         S.row_div = T;
         EpiGates e{L.ZR, L.h, L.q, L.czr, C};
+        PROF("gemm_gates", st);
         TRY(launch_gemm_gates(S, M, 2 * C, e, st));
     }
     // 4. candidate state, GRU blend and attention-weighted sum over periods -> hidden (N,C)
@@ -199,6 +240,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         a.S.row_div = T;
         a.num_nodes = N; a.T = T; a.C = C;
         a.bias = L.ch; a.ZR = L.ZR; a.h = L.h; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
+        PROF("gemm_candidate", st);
         TRY(launch_gemm_candidate(a, st));
     }
     // 5. head: relu -> linear1 -> relu -> linear2
@@ -208,6 +250,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         S.seg[0] = make_seg(hidden, C, p.head1_w, nullptr, C, INT_MAX, C, true, SEG_RELU_A);
         S.row_div = 1;
         EpiBiasAct e{L.y1, H1, p.head1_b, ACT_RELU, 0.f};
+        PROF("head_fwd", st);
         TRY(launch_gemm_bias_act(S, N, H1, e, st));
         GemmSegs S2{};
         S2.nseg = 1;
@@ -220,10 +263,14 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
 }
 
 // out[Nout x Nin] (+ column sums) = P^T Q over uniform chunks, reduced deterministically.
-int wgrad_full(const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu, long M, int kchunk,
-               int nchunks, float* slab, float* out, long ldo, float* colsum, hipStream_t st) {
+int wgrad_full(const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu, long M,
+               int kchunk, int nchunks, float* slab, float* out, long ldo, float* colsum, hipStream_t st) {
     WgradArgs a{P, ldp, Nout, Q, ldq, Nin, q_relu, M, kchunk, nullptr, nchunks, slab, colsum ? 1 : 0};
-    TRY(launch_wgrad(a, st));
+    {
+        PROF(name, st);
+        TRY(launch_wgrad(a, st));
+    }
+    PROF("wgrad_reduce", st);
     WgradReduceArgs r{};
     r.slab = slab; r.nchunks = nchunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
     r.Nout = Nout; r.Nin = Nin; r.chunk_group = nullptr; r.ngroups = 1; r.out = out; r.ldo = ldo; r.group_stride = 0;
@@ -232,31 +279,36 @@ int wgrad_full(const float* P, long ldp, int Nout, const float* Q, long ldq, int
 }
 
 int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
-                  const float* dpred, const float* dhidden, const float* hidden, const Layout& L, hipStream_t st) {
+                  const float* dpred, const float* dhidden, const float* hidden, const float* xp_ext, const Layout& L,
+                  hipStream_t st) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
     const long M = (long)N * T;
+    const float* Xp = xp_ext ? xp_ext : L.Xp;
     // ---- head ----------------------------------------------------------------------------------
-    TRY(wgrad_full(dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
+    TRY(wgrad_full("wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
     {   // d1 = (dpred A2) * (y1 > 0)
         GemmSegs S{};
         S.nseg = 1;
         S.seg[0] = make_seg(dpred, O, p.head2_w, nullptr, H1, INT_MAX, O, false);
         S.row_div = 1;
         EpiMaskAdd e{L.d1, H1, L.y1, H1, nullptr, 0};
+        PROF("head_bwd", st);
         TRY(launch_gemm_mask_add(S, N, H1, e, st));
     }
-    TRY(wgrad_full(L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head1_w, C, gr.head1_b, st));
+    TRY(wgrad_full("wgrad_head1", L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head1_w, C, gr.head1_b, st));
     {   // dOH = (d1 A1) * (hidden > 0) + dhidden
         GemmSegs S{};
         S.nseg = 1;
         S.seg[0] = make_seg(L.d1, H1, p.head1_w, nullptr, C, INT_MAX, H1, false);
         S.row_div = 1;
         EpiMaskAdd e{L.dOH, C, hidden, C, dhidden, C};
+        PROF("head_bwd", st);
         TRY(launch_gemm_mask_add(S, N, C, e, st));
     }
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, L.h, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
+        PROF("cell_bwd", st);
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
     }
@@ -266,6 +318,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad1 e{L.h, L.ZR, L.dOH, L.probs, L.dzr, L.dh, C, T};
+        PROF("dgrad_candidate", st);
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
     }
     {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
@@ -275,14 +328,19 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad2 e{L.dh, L.h, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        PROF("dgrad_gates", st);
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
-    TRY(wgrad_full(L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
-    TRY(wgrad_full(L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGh, F, nullptr, st));
+    TRY(wgrad_full("wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
+    TRY(wgrad_full("wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGh, F, nullptr, st));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, L.h, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
-        TRY(launch_wgrad(a, st));
+        {
+            PROF("wgrad_Uzr", st);
+            TRY(launch_wgrad(a, st));
+        }
+        PROF("wgrad_reduce", st);
         for (int k = 0; k < 2; ++k) {
             WgradReduceArgs r{};
             r.slab = L.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a);
@@ -292,24 +350,29 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(launch_wgrad_reduce(r, st));
         }
     }
-    TRY(wgrad_full(L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGzr, F, nullptr, st));
+    TRY(wgrad_full("wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGzr, F, nullptr, st));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
-    TRY(wgrad_full(L.dh, C, C, L.Xp, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dA0, F, dbpr, st));
+    TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dA0, F, dbpr, st));
     if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, L.slab, 0};
-        TRY(launch_wgrad(a, st));
+        {
+            PROF("wgrad_Ar", st);
+            TRY(launch_wgrad(a, st));
+        }
+        PROF("wgrad_reduce", st);
         WgradReduceArgs r{};
         r.slab = L.slab; r.nchunks = g.n_chunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
         r.Nout = C; r.Nin = F; r.chunk_group = g.chunk_region; r.ngroups = R; r.out = dAall; r.ldo = F;
         r.group_stride = (long)C * F;
         TRY(launch_wgrad_reduce(r, st));
     } else {
-        TRY(wgrad_full(L.dh, C, C, L.LX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dAall, F, nullptr, st));
+        TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dAall, F, nullptr, st));
     }
     // ---- back through the weight compositions (tiny) --------------------------------------------------
+    PROF("compose_bwd", st);
     for (int k = 0; k < 3; ++k) {
         const float* dG = k < 2 ? L.dGzr + (long)k * C * F : L.dGh;
         const float* dc = k < 2 ? L.dczr + (long)k * C : L.dch;
@@ -421,7 +484,7 @@ int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, 
     REGT_CHECK_ARG(dOut && A && dW && slab && M > 0 && N > 0 && K > 0, "regt_wgrad: bad argument");
     int kc, nc;
     wgrad_chunks(M, &kc, &nc);
-    return wgrad_full(dOut, ldd, N, A, lda, K, 0, M, kc, nc, slab, dW, ldw, dbias, (hipStream_t)st);
+    return wgrad_full("wgrad", dOut, ldd, N, A, lda, K, 0, M, kc, nc, slab, dW, ldw, dbias, (hipStream_t)st);
 }
 
 size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks) {
@@ -429,21 +492,36 @@ size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks) {
     return make_layout(*dims, n_chunks, nullptr).bytes;
 }
 
-int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x, float* pred,
-                     float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
+                              const float* xp_ext, int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes,
+                              regt_stream_t st) {
     TRY(check_dims(dims));
     REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && graph->node_region, "regt_forward: graph incomplete");
     TRY(check_ptrs(params, *dims));
-    REGT_CHECK_ARG(x && pred && hidden && ws, "regt_forward: NULL pointer");
-    REGT_CHECK_ARG(al16(x) && al16(hidden) && al16(ws), "regt_forward: x, hidden and workspace must be 16-byte aligned");
+    REGT_CHECK_ARG((x || xp_ext) && pred && hidden && ws, "regt_forward: NULL pointer");
+    REGT_CHECK_ARG(al16(x) && al16(xp_ext) && al16(hidden) && al16(ws),
+                   "regt_forward: x, hidden and workspace must be 16-byte aligned");
+    REGT_CHECK_ARG(!xp_ext || x_rows >= dims->N, "regt_forward_packed: x_rows=%d < N=%d", x_rows, dims->N);
     Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
-    return forward_impl(*dims, *graph, *params, x, pred, hidden, L, (hipStream_t)st);
+    return forward_impl(*dims, *graph, *params, x, xp_ext, x_rows, pred, hidden, L, (hipStream_t)st);
+}
+
+int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x, float* pred,
+                     float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG(x != nullptr, "regt_forward: x is NULL");
+    return forward_common(dims, graph, params, x, nullptr, 0, pred, hidden, ws, ws_bytes, st);
+}
+
+int32_t regt_forward_packed(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x_packed,
+                            int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG(x_packed != nullptr, "regt_forward_packed: x_packed is NULL");
+    return forward_common(dims, graph, params, nullptr, x_packed, x_rows, pred, hidden, ws, ws_bytes, st);
 }
 
 int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const regt_grads* grads,
-                      const float* dpred, const float* dhidden, const float* hidden, void* ws, size_t ws_bytes,
-                      regt_stream_t st) {
+                      const float* dpred, const float* dhidden, const float* hidden, const float* x_packed, void* ws,
+                      size_t ws_bytes, regt_stream_t st) {
     TRY(check_dims(dims));
     REGT_CHECK_ARG(graph && graph->rowptr && graph->node_region, "regt_backward: graph incomplete");
     TRY(check_ptrs(params, *dims));
@@ -457,7 +535,39 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
     }
     Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
-    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, L, (hipStream_t)st);
+    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, (hipStream_t)st);
+}
+
+int32_t regt_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return REGT_OK;
+}
+
+/* Waits for all recorded events, writes one line per stage "name count total_ms\n" into buf, clears the records. */
+int32_t regt_profile_collect(char* buf, size_t buf_bytes) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto& a = agg[r.name];
+            a.first += 1;
+            a.second += ms;
+        }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    g_prof.clear();
+    std::string out;
+    char line[160];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    REGT_CHECK_ARG(buf && buf_bytes > out.size(), "regt_profile_collect: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return REGT_OK;
 }
 
 int32_t regt_mse_loss_grad(const float* pred, const float* y, float* dpred, float* loss_out, int64_t count,

@@ -1,0 +1,153 @@
+"""Region-sharded multi-GPU execution: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+
+The reference is single-process; this layer is new design:
+
+* nodes are partitioned by region blocks -- rank g owns a contiguous node range; all dense work
+  (GEMMs, gates, head, loss partial sums) and the regional ChebConv aggregation are local because
+  regional edges never leave a region;
+* the only cross-rank dependency is the full-graph GCN aggregation ``A_hat x`` for in-edges whose
+  source lives on another rank.  ``x`` is input data, so ONE all-gather of the packed *boundary rows*
+  (nodes that have an out-edge into another shard) per snapshot suffices, and there is no sparse
+  backward traffic at all (A_hat x is constant w.r.t. the parameters);
+* gradients are summed with one flat-buffer all-reduce per optimiser step (the reference steps the
+  optimiser once per epoch, run.py:194).
+
+``ShardTopology`` is pure index logic (numpy, runs anywhere -- covered by gloo tests on CPU);
+``build_shard`` adds the GPU graph preparation.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .graph import PreparedGraph, cheb_edge_weights, gcn_csr, node_regions, raw_csr
+
+
+@dataclass
+class ShardTopology:
+    rank: int
+    world: int
+    node_lo: int
+    node_hi: int
+    boundary: List[np.ndarray]     # per rank: sorted global ids of its boundary nodes
+    max_boundary: int
+
+    @property
+    def n_local(self) -> int:
+        return self.node_hi - self.node_lo
+
+    @property
+    def x_rows(self) -> int:
+        """Rows of the extended packed input: own nodes, then world * max_boundary gathered rows."""
+        return self.n_local + self.world * self.max_boundary
+
+    def send_index(self) -> np.ndarray:
+        """Local row ids to send (own boundary nodes), padded with row 0 to max_boundary."""
+        idx = np.zeros(self.max_boundary, dtype=np.int64)
+        own = self.boundary[self.rank] - self.node_lo
+        idx[:own.size] = own
+        return idx
+
+    def remap_columns(self, cols: np.ndarray, owner_bounds: np.ndarray) -> np.ndarray:
+        """Global source ids -> row ids of the extended packed input of this rank."""
+        cols = np.asarray(cols, dtype=np.int64)
+        out = np.empty_like(cols)
+        local = (cols >= self.node_lo) & (cols < self.node_hi)
+        out[local] = cols[local] - self.node_lo
+        rem = ~local
+        if rem.any():
+            owner = np.searchsorted(owner_bounds, cols[rem], side="right") - 1
+            pos = np.empty(owner.size, dtype=np.int64)
+            for r in np.unique(owner):
+                m = owner == r
+                p = np.searchsorted(self.boundary[r], cols[rem][m])
+                if (p >= self.boundary[r].size).any() or (self.boundary[r][np.minimum(p, self.boundary[r].size - 1)] != cols[rem][m]).any():
+                    raise RuntimeError("halo source is not in its owner's boundary set")
+                pos[m] = p
+            out[rem] = self.n_local + owner * self.max_boundary + pos
+        return out
+
+
+def shard_topology(edge_index: np.ndarray, owner_bounds: np.ndarray, rank: int, world: int) -> ShardTopology:
+    """``owner_bounds`` (world+1,) contiguous node ownership; every rank computes the same boundary sets."""
+    src, dst = np.asarray(edge_index[0], dtype=np.int64), np.asarray(edge_index[1], dtype=np.int64)
+    so = np.searchsorted(owner_bounds, src, side="right") - 1
+    do = np.searchsorted(owner_bounds, dst, side="right") - 1
+    cross = (so != do) & (src != dst)
+    boundary = [np.unique(src[cross & (so == r)]) for r in range(world)]
+    mb = max(1, max(b.size for b in boundary))
+    return ShardTopology(rank, world, int(owner_bounds[rank]), int(owner_bounds[rank + 1]), boundary, mb)
+
+
+def exchange_boundary_rows(xp_ext: torch.Tensor, topo: ShardTopology, send_idx: torch.Tensor, group=None):
+    """All-gather the packed boundary rows into rows [n_local, x_rows) of ``xp_ext`` (in place).
+
+    ``xp_ext``: (x_rows, W) with the rank's own packed rows already in [0, n_local).  Works with the
+    'nccl' (RCCL) backend on GPU tensors and with 'gloo' on CPU tensors (tests)."""
+    if topo.world == 1:
+        return xp_ext
+    send = xp_ext.index_select(0, send_idx)                       # (max_boundary, W)
+    recv = xp_ext[topo.n_local:]                                   # (world*max_boundary, W), contiguous view
+    if xp_ext.is_cuda:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        parts = list(recv.view(topo.world, topo.max_boundary, -1).unbind(0))
+        dist.all_gather(parts, send, group=group)
+    return xp_ext
+
+
+def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
+    """One flat-buffer sum all-reduce of all gradients (3-19 MB here: latency-bound on xGMI, so one call)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+@dataclass
+class Shard:
+    topo: ShardTopology
+    graph: PreparedGraph           # local stacked operator; A_hat columns index the extended input
+    send_idx: torch.Tensor         # (max_boundary,) int64 on the device
+
+
+def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], region_attr: Sequence[torch.Tensor],
+                num_nodes: int, owner_bounds: np.ndarray, region_owner: Sequence[int], rank: int, world: int,
+                device, gcn_weight: Optional[torch.Tensor] = None) -> Shard:
+    """GPU graph preparation for one rank.  ``edge_index`` etc. are the GLOBAL graph (host tensors);
+    ``region_owner[r]`` is the rank that owns region r (its nodes lie inside that rank's range)."""
+    topo = shard_topology(edge_index.cpu().numpy(), owner_bounds, rank, world)
+    lo, hi = topo.node_lo, topo.node_hi
+    # global A_hat (global degrees), then keep the rows of the owned nodes
+    rp, col, val = gcn_csr(edge_index.to(device), None if gcn_weight is None else gcn_weight.to(device), num_nodes)
+    rp_h = rp.cpu().numpy().astype(np.int64)
+    b, e = rp_h[lo], rp_h[hi]
+    col_loc = topo.remap_columns(col[b:e].cpu().numpy(), owner_bounds)
+    rp_a = torch.from_numpy((rp_h[lo:hi + 1] - b).astype(np.int32)).to(device)
+    col_a = torch.from_numpy(col_loc.astype(np.int32)).to(device)
+    val_a = val[b:e].contiguous()
+    # regional Laplacians of the owned regions, in local ids
+    mine = [r for r in range(len(region_index)) if region_owner[r] == rank]
+    loc_idx = [(region_index[r] - lo).to(device) for r in mine]
+    loc_w = [region_attr[r].to(device) for r in mine]
+    n_loc = hi - lo
+    w_all = [cheb_edge_weights(ei, ew, n_loc) for ei, ew in zip(loc_idx, loc_w)]
+    owner = node_regions([t.cpu() for t in loc_idx], n_loc)
+    rp_l, col_l, val_l = raw_csr(torch.cat(loc_idx, dim=1), torch.cat(w_all), n_loc)
+    nnz_a = int(col_a.numel())
+    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(mine),
+                          rowptr=torch.cat([rp_a, rp_l[1:] + nnz_a]).contiguous(),
+                          col=torch.cat([col_a, col_l]).contiguous(), val=torch.cat([val_a, val_l]).contiguous(),
+                          node_region=torch.from_numpy(owner).to(device), node_region_host=owner,
+                          nnz_gcn=nnz_a, nnz_cheb=int(col_l.numel()))
+    return Shard(topo, graph, torch.from_numpy(topo.send_index()).to(device))

@@ -66,7 +66,10 @@ class RegTGCNFunction(torch.autograd.Function):
     """(x, *params) -> (pred (N,O), hidden (N,C)); whole-model forward and backward in HIP."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, graph: PreparedGraph, regional: bool, slope: float, *params: torch.Tensor):
+    def forward(ctx, x: torch.Tensor, graph: PreparedGraph, regional: bool, slope: float, packed: bool,
+                *params: torch.Tensor):
+        """``packed`` False: x is the reference's (N,F,T) snapshot.  True: x is the extended packed input
+        (x_rows >= N, T, F) of the region-sharded path (own rows first, halo rows after; see dist.py)."""
         lib = _lib.load()
         if not x.is_cuda:
             raise _lib.RegtError("RegT-GCN forward needs CUDA/HIP tensors: there is no CPU path in this package")
@@ -79,9 +82,16 @@ class RegTGCNFunction(torch.autograd.Function):
             if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
                 raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
         x = x.contiguous()
-        N, F, T = x.shape
-        if N != graph.num_nodes:
-            raise ValueError(f"x has {N} nodes but the prepared graph has {graph.num_nodes}")
+        if packed:
+            x_rows, T, F = x.shape
+            N = graph.num_nodes
+            if x_rows < N:
+                raise ValueError(f"packed input has {x_rows} rows but the shard owns {N} nodes")
+        else:
+            N, F, T = x.shape
+            x_rows = N
+            if N != graph.num_nodes:
+                raise ValueError(f"x has {N} nodes but the prepared graph has {graph.num_nodes}")
         tens = dict(zip(names, params))
         Cdim = tens["tgnn.conv.bias"].numel()
         O = tens["linear2.weight"].shape[0]
@@ -106,9 +116,14 @@ class RegTGCNFunction(torch.autograd.Function):
         pred = torch.empty(N, O, dtype=torch.float32, device=x.device)
         hidden = torch.empty(N, Cdim, dtype=torch.float32, device=x.device)
         ps = _fill(_lib.Params(), tens, regional)
-        _lib.check(lib.regt_forward(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), _lib.ptr(pred), _lib.ptr(hidden),
-                                    _lib.ptr(ws), wsb, _stream()), "regt_forward")
+        if packed:
+            _lib.check(lib.regt_forward_packed(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), x_rows, _lib.ptr(pred),
+                                               _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward_packed")
+        else:
+            _lib.check(lib.regt_forward(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), _lib.ptr(pred),
+                                        _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward")
         ctx.graph, ctx.regional, ctx.dims, ctx.ws, ctx.wsb = graph, regional, dims, ws, wsb
+        ctx.xp = x if packed else None
         ctx.names = names
         ctx.save_for_backward(hidden, *params)
         return pred, hidden
@@ -129,11 +144,11 @@ class RegTGCNFunction(torch.autograd.Function):
         ps = _fill(_lib.Params(), tens, regional)
         gr = _fill(_lib.Grads(), grads, regional)
         _lib.check(lib.regt_backward(C.byref(dims), C.byref(gs), C.byref(ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
-                                     _lib.ptr(hidden), _lib.ptr(ctx.ws), ctx.wsb, _stream()), "regt_backward")
-        return (None, None, None, None) + tuple(grads[n_] for n_ in names)
+                                     _lib.ptr(hidden), _lib.ptr(ctx.xp), _lib.ptr(ctx.ws), ctx.wsb, _stream()), "regt_backward")
+        return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
 
 
 def regt_gcn_forward(x, graph: PreparedGraph, params: Dict[str, torch.Tensor], regional: bool = True, slope: float = 0.01):
     """Functional entry: ``params`` keyed by the reference's state_dict names."""
     names = param_names(regional)
-    return RegTGCNFunction.apply(x, graph, regional, slope, *[params[n] for n in names])
+    return RegTGCNFunction.apply(x, graph, regional, slope, False, *[params[n] for n in names])

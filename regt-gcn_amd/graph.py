@@ -174,13 +174,11 @@ def node_regions(region_index: Sequence[torch.Tensor], num_nodes: int) -> np.nda
         owner[dst] = r
     # nodes without regional in-edges have an all-zero Laplacian row: attach them to the previous
     # node's region so that region runs (and wgrad chunks) stay long.
-    last = 0
-    for i in range(num_nodes):
-        if owner[i] < 0:
-            owner[i] = last
-        else:
-            last = owner[i]
-    return owner
+    have = owner >= 0
+    idx = np.where(have, np.arange(num_nodes), -1)
+    np.maximum.accumulate(idx, out=idx)            # index of the last owned node at or before i
+    filled = np.where(idx >= 0, owner[np.maximum(idx, 0)], 0)
+    return filled.astype(np.int32)
 
 
 def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], region_index: Sequence[torch.Tensor],

@@ -147,8 +147,13 @@ class _FusedModel(nn.Module):
         named = dict(self.named_parameters())
         return [named[n] for n in param_names(self.regional)]
 
-    def _run(self, x: torch.Tensor, graph: PreparedGraph):
-        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, *self._params_in_order())
+    def _run(self, x: torch.Tensor, graph: PreparedGraph, packed: bool = False):
+        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, packed, *self._params_in_order())
+
+    def forward_packed(self, x_packed_ext: torch.Tensor, graph: PreparedGraph):
+        """Region-sharded entry: ``x_packed_ext`` (x_rows, T, F) = own packed rows + gathered halo rows (dist.py)."""
+        _need_cuda(x_packed_ext)
+        return self._run(x_packed_ext, graph, packed=True)
 
 
 class RegionalTemporalGCN(_FusedModel):
