@@ -9,25 +9,54 @@
 
 namespace regt {
 
-// ---- epilogue functors --------------------------------------------------------------------------
+// ---- epilogue functors ---------------------------------------------------------------------------
+// Each functor has a scalar form (m, c, v) used when the output is not 16-byte tileable (e.g. the
+// (N, O) head output) and a vector form: load() fetches the auxiliary operands of one float4,
+// apply() finishes and stores it (driver: GemmCore::for_each_vec).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#define REGT_V4(expr_x) make_float4(expr_x(x), expr_x(y), expr_x(z), expr_x(w))
+
 struct EpiBiasActF {
     EpiBiasAct e;
+    // none / leaky_relu / relu are all "v > 0 ? v : v * ns" with ns = 1 / slope / 0
+    __device__ __forceinline__ float act(float v) const {
+        const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
+        return v > 0.f ? v : v * ns;
+    }
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
-        v += e.bias ? e.bias[c] : 0.f;
-        if (e.act == ACT_LRELU) v = v > 0.f ? v : v * e.slope;
-        else if (e.act == ACT_RELU) v = fmaxf(v, 0.f);
-        e.out[m * e.ldo + c] = v;
+        e.out[m * e.ldo + c] = act(v + (e.bias ? e.bias[c] : 0.f));
+    }
+    struct Aux { float4 b; };
+    __device__ __forceinline__ Aux load(long, int c) const { return Aux{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) act(v.k + a.b.k)
+        st4(e.out + m * e.ldo + c, REGT_V4(F_));
+#undef F_
     }
 };
 struct EpiGatesF {
     EpiGates e;
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
-        float g = 1.0f / (1.0f + expf(-(v + e.bias[c])));
+        float g = fast_sigmoid(v + e.bias[c]);
         e.ZR[m * (2L * e.C) + c] = g;
-        if (c >= e.C) {
-            int cc = c - e.C;
-            e.q[m * e.C + cc] = e.h[m * e.C + cc] * g;
-        }
+        if (c >= e.C) e.q[m * e.C + c - e.C] = e.h[m * e.C + c - e.C] * g;
+    }
+    struct Aux { float4 b, h; };
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        Aux a;
+        a.b = ld4(e.bias + c);
+        a.h = c >= e.C ? ld4(e.h + m * e.C + c - e.C) : make_float4(0, 0, 0, 0);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) fast_sigmoid(v.k + a.b.k)
+        const float4 g = REGT_V4(F_);
+#undef F_
+        st4(e.ZR + m * (2L * e.C) + c, g);
+        if (c >= e.C) st4(e.q + m * e.C + c - e.C, make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w));
     }
 };
 struct EpiDgrad1F {
@@ -41,6 +70,25 @@ struct EpiDgrad1F {
         e.dzr[m * (2L * e.C) + e.C + c] = v * hv * (R * (1.0f - R));
         e.dh[m * e.C + c] = v * R + e.probs[t] * e.dOH[node * e.C + c] * Z;
     }
+    struct Aux { float4 h, Z, R, d; float p; };
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        const long node = m / e.T;
+        Aux a;
+        a.p = e.probs[(int)(m - node * e.T)];
+        a.h = ld4(e.h + m * e.C + c);
+        a.Z = ld4(e.ZR + m * (2L * e.C) + c);
+        a.R = ld4(e.ZR + m * (2L * e.C) + e.C + c);
+        a.d = ld4(e.dOH + node * e.C + c);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+        st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
+#undef F_
+#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+        st4(e.dh + m * e.C + c, REGT_V4(F_));
+#undef F_
+    }
 };
 struct EpiDgrad2F {
     EpiDgrad2 e;
@@ -50,6 +98,18 @@ struct EpiDgrad2F {
         if (e.act == ACT_LRELU) d = e.h[i] > 0.f ? d : d * e.slope;
         e.dh[i] = d;
     }
+    struct Aux { float4 d, h; };
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        Aux a;
+        a.d = ld4(e.dh + m * e.C + c);
+        a.h = e.act == ACT_LRELU ? ld4(e.h + m * e.C + c) : make_float4(1, 1, 1, 1);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) ((a.d.k + v.k) * (a.h.k > 0.f ? 1.0f : e.slope))
+        st4(e.dh + m * e.C + c, REGT_V4(F_));
+#undef F_
+    }
 };
 struct EpiMaskAddF {
     EpiMaskAdd e;
@@ -58,10 +118,22 @@ struct EpiMaskAddF {
         if (e.add) o += e.add[m * e.ldadd + c];
         e.out[m * e.ldo + c] = o;
     }
+    struct Aux { float4 mk, ad; };
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        Aux a;
+        a.mk = ld4(e.mask + m * e.ldm + c);
+        a.ad = e.add ? ld4(e.add + m * e.ldadd + c) : make_float4(0, 0, 0, 0);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) ((a.mk.k > 0.f ? v.k : 0.f) + a.ad.k)
+        st4(e.out + m * e.ldo + c, REGT_V4(F_));
+#undef F_
+    }
 };
 
 template <class EpiF>
-__global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, int N, EpiF epi) {
+__global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, int N, EpiF epi, int vec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -78,43 +150,54 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     core.run(acc);
-    core.for_each(acc, [&](int r, int c, float v) { epi(m0 + r, c, v); });
+    if (vec) core.for_each_vec(acc, epi);
+    else core.for_each(acc, [&](int r, int c, float v) { epi(m0 + r, c, v); });
 }
 
 template <class EpiF>
-static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, hipStream_t st) {
+static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, bool vec, hipStream_t st) {
     REGT_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%ld N=%d", M, N);
     long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-    static bool attr_set = false;
-    (void)attr_set;
     REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_flat_kernel<EpiF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-    hipLaunchKernelGGL(gemm_flat_kernel<EpiF>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, S, M, N, f);
+    hipLaunchKernelGGL(gemm_flat_kernel<EpiF>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, S, M, N, f, vec ? 1 : 0);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
 
+static inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st) {
-    return launch_flat(S, M, N, EpiBiasActF{e}, st);
+    const bool vec = N % 4 == 0 && e.ldo % 4 == 0 && a16(e.out) && a16(e.bias);
+    return launch_flat(S, M, N, EpiBiasActF{e}, vec, st);
 }
 int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st) {
     REGT_CHECK_ARG(N == 2 * e.C, "gates gemm expects N == 2C");
-    return launch_flat(S, M, N, EpiGatesF{e}, st);
+    const bool vec = e.C % 4 == 0 && a16(e.ZR) && a16(e.h) && a16(e.q) && a16(e.bias);
+    return launch_flat(S, M, N, EpiGatesF{e}, vec, st);
 }
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
-    return launch_flat(S, M, N, EpiDgrad1F{e}, st);
+    const bool vec = e.C % 4 == 0 && a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh);
+    return launch_flat(S, M, N, EpiDgrad1F{e}, vec, st);
 }
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");
-    return launch_flat(S, M, N, EpiDgrad2F{e}, st);
+    const bool vec = e.C % 4 == 0 && a16(e.dh) && a16(e.h);
+    return launch_flat(S, M, N, EpiDgrad2F{e}, vec, st);
 }
 int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, hipStream_t st) {
-    return launch_flat(S, M, N, EpiMaskAddF{e}, st);
+    const bool vec = N % 4 == 0 && e.ldo % 4 == 0 && e.ldm % 4 == 0 && (!e.add || e.ldadd % 4 == 0) && a16(e.out) &&
+                     a16(e.mask) && a16(e.add);
+    return launch_flat(S, M, N, EpiMaskAddF{e}, vec, st);
 }
 
 // ---- candidate state, T loop inside the workgroup ------------------------------------------------
+// Per period t: Ht = tanh(q_t Uh2^T + (A_hat x)_t Gh^T + ch) is stored for the backward pass, blended
+// with the gate (Z*h + (1-Z)*Ht) and accumulated with the attention probability p_t in registers;
+// the hidden state (N, C) is written once after the last period.
+template <bool VEC>
 __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (a.C + GBN - 1) / GBN;
@@ -122,45 +205,115 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
     const int i0 = (bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
-    f32x16 acc[2][2], oh[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oh[i][j][r] = 0.f;
     const long C = a.C;
-    for (int t = 0; t < a.T; ++t) {
-        RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
-        GemmCore core(a.S, rm, n0, a.C, lds);
+    f32x16 acc[2][2];
+    if constexpr (VEC) {
+        float4 oh[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oh[i] = make_float4(0, 0, 0, 0);
+        for (int t = 0; t < a.T; ++t) {
+            RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
+            GemmCore core(a.S, rm, n0, a.C, lds);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            core.run(acc);
+            core.stage(acc);
+            const float pt = a.probs[t];
+            const int c = core.ecol();
+            if (c < a.C) {
+                const float4 b = ld4(a.bias + c);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 Z[4], hv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = core.erow(4 * g + j);
+                        if (r < nvalid) {
+                            const long m = rm.grow(r);
+                            Z[j] = ld4(a.ZR + m * 2 * C + c);
+                            hv[j] = ld4(a.h + m * C + c);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = core.erow(4 * g + j);
+                        if (r < nvalid) {
+                            const long m = rm.grow(r);
+                            const float4 v = core.eread(4 * g + j);
+#define F_(k) fast_tanh(v.k + b.k)
+                            const float4 ht = REGT_V4(F_);
+#undef F_
+                            st4(a.Ht + m * C + c, ht);
+                            float4& o = oh[4 * g + j];
+                            o.x += pt * (Z[j].x * hv[j].x + (1.0f - Z[j].x) * ht.x);
+                            o.y += pt * (Z[j].y * hv[j].y + (1.0f - Z[j].y) * ht.y);
+                            o.z += pt * (Z[j].z * hv[j].z + (1.0f - Z[j].z) * ht.z);
+                            o.w += pt * (Z[j].w * hv[j].w + (1.0f - Z[j].w) * ht.w);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int c = n0 + 4 * (threadIdx.x & 31);
+        if (c < a.C) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = (threadIdx.x >> 5) + 8 * i;
+                if (r < nvalid) st4(a.OH + (long)(i0 + r) * C + c, oh[i]);
+            }
+        }
+    } else {
+        f32x16 oh[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        core.run(acc);
-        const float pt = a.probs[t];
-        core.for_each2(acc, oh, [&](int r, int c, float v, float o) {
-            long m = rm.grow(r);
-            float ht = tanhf(v + a.bias[c]);
-            a.Ht[m * C + c] = ht;
-            float Z = a.ZR[m * 2 * C + c];
-            float hv = a.h[m * C + c];
-            return o + pt * (Z * hv + (1.0f - Z) * ht);
-        });
+                for (int r = 0; r < 16; ++r) oh[i][j][r] = 0.f;
+        for (int t = 0; t < a.T; ++t) {
+            RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
+            GemmCore core(a.S, rm, n0, a.C, lds);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            core.run(acc);
+            const float pt = a.probs[t];
+            core.for_each2(acc, oh, [&](int r, int c, float v, float o) {
+                long m = rm.grow(r);
+                float ht = fast_tanh(v + a.bias[c]);
+                a.Ht[m * C + c] = ht;
+                float Z = a.ZR[m * 2 * C + c];
+                float hv = a.h[m * C + c];
+                return o + pt * (Z * hv + (1.0f - Z) * ht);
+            });
+        }
+        RowMap rm{(long)i0, 1, nvalid};
+        GemmCore core(a.S, rm, n0, a.C, lds);
+        core.for_each(oh, [&](int r, int c, float v) { a.OH[(long)(i0 + r) * C + c] = v; });
     }
-    RowMap rm{(long)i0, 1, nvalid};
-    GemmCore core(a.S, rm, n0, a.C, lds);
-    core.for_each(oh, [&](int r, int c, float v) { a.OH[(long)(i0 + r) * C + c] = v; });
 }
 
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
-    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-    hipLaunchKernelGGL(gemm_cand_kernel, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+    const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias);
+    if (vec) {
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+        hipLaunchKernelGGL(gemm_cand_kernel<true>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+    } else {
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+        hipLaunchKernelGGL(gemm_cand_kernel<false>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+    }
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -343,30 +496,49 @@ int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
 }
 
 // ---- tiny strided batched GEMM --------------------------------------------------------------------
-__global__ void small_gemm_kernel(SmallGemm g) {
+// One output element per group of 8 adjacent lanes: the K (and summed-batch) range is strided over the
+// group and combined with a fixed xor-shuffle tree (deterministic).  Sizes here are <= 64 x 256 x 256
+// outputs with K <= R*C, so the point is latency (enough waves), not FLOP/s.
+constexpr int SG_SPLIT = 8;
+__global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
     const long per = (long)g.m * g.n;
     const int nb = g.sum_batch ? 1 : g.batch;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < per * nb; idx += (long)gridDim.x * blockDim.x) {
-        int b = (int)(idx / per);
-        long e = idx - (long)b * per;
-        int i = (int)(e / g.n), j = (int)(e % g.n);     // j fastest: coalesced when scj == 1 / sbj == 1
+    const long total = per * nb;
+    const int sub = threadIdx.x % SG_SPLIT;
+    const long stride = (long)gridDim.x * blockDim.x / SG_SPLIT;
+    long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) / SG_SPLIT;
+    long wfirst = idx - (threadIdx.x % 64) / SG_SPLIT;           // wave-uniform loop bound (shuffles inside)
+    for (; wfirst < total; wfirst += stride, idx += stride) {
+        const bool valid = idx < total;
         float s = 0.f;
-        const int b0 = g.sum_batch ? 0 : b, b1 = g.sum_batch ? g.batch : b + 1;
-        for (int bb = b0; bb < b1; ++bb) {
-            const float* A = g.A + (long)bb * g.sab + (long)i * g.sai;
-            const float* B = g.B + (long)bb * g.sbb + (long)j * g.sbj;
-            for (int k = 0; k < g.k; ++k) s += A[(long)k * g.sak] * B[(long)k * g.sbk];
+        int b = 0, i = 0, j = 0;
+        if (valid) {
+            b = (int)(idx / per);
+            const long e = idx - (long)b * per;
+            i = (int)(e / g.n);
+            j = (int)(e % g.n);                                   // j fastest: coalesced when scj == 1 / sbj == 1
+            const int b0 = g.sum_batch ? 0 : b, b1 = g.sum_batch ? g.batch : b + 1;
+            for (int bb = b0; bb < b1; ++bb) {
+                const float* A = g.A + (long)bb * g.sab + (long)i * g.sai;
+                const float* B = g.B + (long)bb * g.sbb + (long)j * g.sbj;
+                for (int k = sub; k < g.k; k += SG_SPLIT) s = fmaf(A[(long)k * g.sak], B[(long)k * g.sbk], s);
+            }
         }
-        float* c = g.C + (long)b * g.scb + (long)i * g.sci + (long)j * g.scj;
-        *c = g.accumulate ? *c + s : s;
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (valid && sub == 0) {
+            float* c = g.C + (long)b * g.scb + (long)i * g.sci + (long)j * g.scj;
+            *c = g.accumulate ? *c + s : s;
+        }
     }
 }
 
 int launch_small_gemm(const SmallGemm& g, hipStream_t st) {
     REGT_CHECK_ARG(g.m > 0 && g.n > 0 && g.batch > 0, "small_gemm: empty problem");
-    long total = (long)g.m * g.n * (g.sum_batch ? 1 : g.batch);
+    long total = (long)g.m * g.n * (g.sum_batch ? 1 : g.batch) * SG_SPLIT;
     int blocks = cdiv(total, 256);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(small_gemm_kernel, dim3(blocks), dim3(256), 0, st, g);
     REGT_CHECK_LAUNCH();
     return REGT_OK;

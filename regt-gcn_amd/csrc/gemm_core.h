@@ -85,7 +85,7 @@ struct GemmCore {
     float* lds;
     int tid, lane, wr, wc;
 
-    __device__ GemmCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_)
+    __device__ __forceinline__ GemmCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_)
         : S(s), rm(r), n0(n0_), N(N_), rmin(0), rmax(0), lds(lds_) {
         tid = threadIdx.x;
         lane = tid & 63;
@@ -95,9 +95,9 @@ struct GemmCore {
     }
 
     // Region range of the tile rows (wave-uniform result, via LDS).  Call once before run().
-    __device__ void find_regions() {
+    __device__ __forceinline__ void find_regions() {
         bool any = false;
-        for (int s = 0; s < S.nseg; ++s) any |= (S.seg[s].flags & SEG_REGION) != 0;
+        for (int s = 0; s < S.nseg; ++s) any |= (pick(s).flags & SEG_REGION) != 0;
         if (!any) return;
         int* red = reinterpret_cast<int*>(lds);
         if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
@@ -114,9 +114,22 @@ struct GemmCore {
         if (rmax < rmin) { rmin = 0; rmax = -1; }
     }
 
+    // Field-wise select instead of S.seg[s]: a dynamically indexed kernel-argument struct would be
+    // copied to scratch; scalar selects keep the descriptors in SGPRs.
+    __device__ __forceinline__ GemmSeg pick(int s) const {
+        GemmSeg g;
+#define REGT_PICK(f) g.f = s == 0 ? S.seg[0].f : (s == 1 ? S.seg[1].f : S.seg[2].f)
+        REGT_PICK(A); REGT_PICK(lda); REGT_PICK(B0); REGT_PICK(B1); REGT_PICK(ldb); REGT_PICK(nsplit);
+        REGT_PICK(K); REGT_PICK(flags); REGT_PICK(b_region_stride);
+#undef REGT_PICK
+        return g;
+    }
+
     __device__ __forceinline__ int seg_iters(int s) const {
-        int nk = (S.seg[s].K + GBK - 1) / GBK;
-        int reps = (S.seg[s].flags & SEG_REGION) ? (rmax - rmin + 1) : 1;
+        const int K = s == 0 ? S.seg[0].K : (s == 1 ? S.seg[1].K : S.seg[2].K);
+        const int fl = s == 0 ? S.seg[0].flags : (s == 1 ? S.seg[1].flags : S.seg[2].flags);
+        int nk = (K + GBK - 1) / GBK;
+        int reps = (fl & SEG_REGION) ? (rmax - rmin + 1) : 1;
         return nk * reps;
     }
 
@@ -128,7 +141,8 @@ struct GemmCore {
             if (it < n) break;
             it -= n;
         }
-        int nk = (S.seg[s].K + GBK - 1) / GBK;
+        const int K = s == 0 ? S.seg[0].K : (s == 1 ? S.seg[1].K : S.seg[2].K);
+        int nk = (K + GBK - 1) / GBK;
         t.seg = s;
         t.region = rmin + it / nk;
         t.k0 = (it % nk) * GBK;
@@ -137,7 +151,7 @@ struct GemmCore {
 
     __device__ __forceinline__ void load_regs(int it, float4 (&ra)[4], float4 (&rb)[4]) const {
         TileIter ti = decode(it);
-        const GemmSeg& g = S.seg[ti.seg];
+        const GemmSeg g = pick(ti.seg);
         const bool region = (g.flags & SEG_REGION) != 0;
         const bool vecA = (g.flags & SEG_VEC_A) != 0, vecB = (g.flags & SEG_VEC_B) != 0;
 #pragma unroll
@@ -184,7 +198,7 @@ struct GemmCore {
     __device__ __forceinline__ void store_lds(int it, int stage, const float4 (&ra)[4], const float4 (&rb)[4]) const {
         float* la = lds + stage * G_STAGE;
         float* lb = la + G_A_TILE;
-        const bool bt = (S.seg[decode(it).seg].flags & SEG_BT) != 0;
+        const bool bt = (pick(decode(it).seg).flags & SEG_BT) != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int slot = tid + 256 * i;
@@ -199,7 +213,7 @@ struct GemmCore {
     __device__ __forceinline__ void compute(int it, int stage, f32x16 (&acc)[2][2]) const {
         const float* la = lds + stage * G_STAGE;
         const float* lb = la + G_A_TILE;
-        const bool bt = (S.seg[decode(it).seg].flags & SEG_BT) != 0;
+        const bool bt = (pick(decode(it).seg).flags & SEG_BT) != 0;
         const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -233,7 +247,7 @@ struct GemmCore {
     }
 
     // acc += sum over all segments.  Ends with a barrier (LDS free for reuse).
-    __device__ void run(f32x16 (&acc)[2][2]) const {
+    __device__ __forceinline__ void run(f32x16 (&acc)[2][2]) const {
         int nit = 0;
         for (int s = 0; s < S.nseg; ++s) nit += seg_iters(s);
         if (nit == 0) return;
@@ -267,6 +281,52 @@ struct GemmCore {
                     }
                 }
             }
+    }
+
+    // ---- LDS-staged epilogue: accumulators -> [128][132] fp32 tile in LDS -> each thread owns the float4
+    // column block (tid & 31) of rows (tid >> 5) + 8*i, i = 0..15.  A wave instruction then touches two
+    // whole 512-B row segments: 16-B vector, fully coalesced global accesses in the epilogue.
+    __device__ __forceinline__ void stage(f32x16 (&acc)[2][2]) const {
+        const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    lds[(wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * G_LDS_KROW + wc * 64 + ni * 32 + lr] =
+                        acc[mi][ni][reg];
+        __syncthreads();
+    }
+    __device__ __forceinline__ int erow(int i) const { return (tid >> 5) + 8 * i; }
+    __device__ __forceinline__ int ecol() const { return n0 + 4 * (tid & 31); }
+    __device__ __forceinline__ float4 eread(int i) const {
+        return *reinterpret_cast<const float4*>(lds + erow(i) * G_LDS_KROW + 4 * (tid & 31));
+    }
+
+    // Vector epilogue driver: f.load(m, c) gathers the auxiliary operands of 4 rows first (loads in
+    // flight together), then f.apply(m, c, v, aux) computes and stores.  m = global row, c = first of 4 columns.
+    template <class F>
+    __device__ __forceinline__ void for_each_vec(f32x16 (&acc)[2][2], const F& f) const {
+        stage(acc);
+        const int c = ecol();
+        if (c < N) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typename F::Aux aux[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = erow(4 * g + j);
+                    if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = erow(4 * g + j);
+                    if (r < rm.nvalid) f.apply(rm.grow(r), c, eread(4 * g + j), aux[j]);
+                }
+            }
+        }
+        __syncthreads();
     }
 
     // Same walk over two accumulators: acc2[..] = f(local_row, global_col, acc[..], acc2[..]).
