@@ -6,8 +6,18 @@
 //   wgrad_reduce_kernel     deterministic reduction of the slabs
 //   small_gemm_kernel       strided batched C = A B for the (C x F)-sized weight compositions
 #include "kernels.h"
+#include "gemm_fast.h"
 
 namespace regt {
+
+// hipFuncSetAttribute is a (slow, host-synchronous) driver call: do it once per kernel, not per launch.
+template <class K>
+static int set_lds_once(K kernel, int bytes, bool* done) {
+    if (*done) return REGT_OK;
+    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    *done = true;
+    return REGT_OK;
+}
 
 // ---- epilogue functors ---------------------------------------------------------------------------
 // Each functor has a scalar form (m, c, v) used when the output is not 16-byte tileable (e.g. the
@@ -154,13 +164,68 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, i
     else core.for_each(acc, [&](int r, int c, float v) { epi(m0 + r, c, v); });
 }
 
+// Fast variant: straight-line K loop with interleaved loads (gemm_fast.h).  Requires vector-aligned
+// operands, one B layout for all segments and N % 4 == 0; everything else takes the generic kernel.
+template <class EpiF, bool BT, bool REGION>
+__global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    FastCore<BT, REGION> core(S, rm, n0, N, lds);
+    core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    core.run(acc, relu_a != 0);
+    core.for_each_vec(acc, epi);
+}
+
+// 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
+static int fast_class(const GemmSegs& S, int N, bool vec) {
+    if (!vec || N % 4 != 0 || S.nseg < 1) return -1;
+    int bt = -1, region = 0, relu = 0;
+    long iters = 0;
+    for (int s = 0; s < S.nseg; ++s) {
+        const GemmSeg& g = S.seg[s];
+        if (!(g.flags & SEG_VEC_A) || !(g.flags & SEG_VEC_B) || g.K % 4 != 0) return -1;
+        const int b = (g.flags & SEG_BT) ? 1 : 0;
+        if (bt >= 0 && bt != b) return -1;
+        bt = b;
+        if (g.flags & SEG_REGION) region = 1;
+        if (g.flags & SEG_RELU_A) relu = 1;
+        iters += (long)cdiv(g.K, GBK) * ((g.flags & SEG_REGION) ? 8 : 1);   // region repeats are bounded per tile below
+    }
+    if (relu && S.nseg != 1) return -1;
+    if (iters > G_MAX_ITERS) return -1;
+    return bt | (region << 1) | (relu << 2);
+}
+
+template <class EpiF, bool BT, bool REGION>
+static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
+    long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
+    REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
+    static bool attr_done = false;
+    if (int rc = set_lds_once(&gemm_flat_fast_kernel<EpiF, BT, REGION>, G_FAST_LDS_BYTES, &attr_done)) return rc;
+    hipLaunchKernelGGL((gemm_flat_fast_kernel<EpiF, BT, REGION>), dim3((unsigned)tiles), dim3(256), G_FAST_LDS_BYTES, st, S, M,
+                       N, f, relu);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 template <class EpiF>
 static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, bool vec, hipStream_t st) {
     REGT_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%ld N=%d", M, N);
     long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_flat_kernel<EpiF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+    static bool attr_done = false;
+    if (int rc = set_lds_once(&gemm_flat_kernel<EpiF>, G_LDS_BYTES, &attr_done)) return rc;
     hipLaunchKernelGGL(gemm_flat_kernel<EpiF>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, S, M, N, f, vec ? 1 : 0);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
@@ -170,26 +235,35 @@ static inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 
 int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st) {
     const bool vec = N % 4 == 0 && e.ldo % 4 == 0 && a16(e.out) && a16(e.bias);
+    const int fc = fast_class(S, N, vec);
+    if (fc >= 0 && (fc & 1)) {
+        if (fc & 2) return launch_fast<EpiBiasActF, true, true>(S, M, N, EpiBiasActF{e}, (fc >> 2) & 1, st);
+        return launch_fast<EpiBiasActF, true, false>(S, M, N, EpiBiasActF{e}, (fc >> 2) & 1, st);
+    }
     return launch_flat(S, M, N, EpiBiasActF{e}, vec, st);
 }
 int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st) {
     REGT_CHECK_ARG(N == 2 * e.C, "gates gemm expects N == 2C");
     const bool vec = e.C % 4 == 0 && a16(e.ZR) && a16(e.h) && a16(e.q) && a16(e.bias);
+    if (fast_class(S, N, vec) == 1) return launch_fast<EpiGatesF, true, false>(S, M, N, EpiGatesF{e}, 0, st);
     return launch_flat(S, M, N, EpiGatesF{e}, vec, st);
 }
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh);
+    if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad1F, false, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad1F{e}, vec, st);
 }
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.dh) && a16(e.h);
+    if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad2F, false, false>(S, M, N, EpiDgrad2F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad2F{e}, vec, st);
 }
 int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, hipStream_t st) {
     const bool vec = N % 4 == 0 && e.ldo % 4 == 0 && e.ldm % 4 == 0 && (!e.add || e.ldadd % 4 == 0) && a16(e.out) &&
                      a16(e.mask) && a16(e.add);
+    if (fast_class(S, N, vec) == 0) return launch_fast<EpiMaskAddF, false, false>(S, M, N, EpiMaskAddF{e}, 0, st);
     return launch_flat(S, M, N, EpiMaskAddF{e}, vec, st);
 }
 
@@ -211,16 +285,18 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
         float4 oh[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) oh[i] = make_float4(0, 0, 0, 0);
+        FastCore<true, false> core(a.S, RowMap{(long)i0 * a.T, a.T, nvalid}, n0, a.C, lds);
+        core.plan();
         for (int t = 0; t < a.T; ++t) {
-            RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
-            GemmCore core(a.S, rm, n0, a.C, lds);
+            const RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
+            core.set_rows(rm);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            core.run(acc);
+            core.run(acc, false);
             core.stage(acc);
             const float pt = a.probs[t];
             const int c = core.ecol();
@@ -304,14 +380,15 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
-    const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias);
+    const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias) &&
+                     fast_class(a.S, a.C, true) == 1;
     if (vec) {
-        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-        hipLaunchKernelGGL(gemm_cand_kernel<true>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+        static bool attr_done = false;
+        if (int rc = set_lds_once(&gemm_cand_kernel<true>, G_FAST_LDS_BYTES, &attr_done)) return rc;
+        hipLaunchKernelGGL(gemm_cand_kernel<true>, dim3((unsigned)tiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
-        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cand_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+        static bool attr_done2 = false;
+        if (int rc = set_lds_once(&gemm_cand_kernel<false>, G_LDS_BYTES, &attr_done2)) return rc;
         hipLaunchKernelGGL(gemm_cand_kernel<false>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
     }
     REGT_CHECK_LAUNCH();
@@ -452,8 +529,8 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
     size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
     if (wide) {
-        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<128>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        static bool attr_done = false;
+        if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
         hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     } else {
         hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);

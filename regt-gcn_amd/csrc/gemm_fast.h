@@ -1,0 +1,261 @@
+// Fast path of the segmented fp32-MFMA GEMM (same tile geometry and LDS images as gemm_core.h).
+//
+// Differences from the generic core, all aimed at keeping the matrix pipe of every SIMD fed:
+//   * the K loop body is ONE straight-line basic block: no layout / guard / segment branches inside.
+//     The (segment, region repeat, k0) walk is precomputed per workgroup into a small descriptor
+//     table in LDS; operand layout (B stored [N][K] or [K][N]) and region masking are template
+//     parameters; all operands are 16-byte vectorisable (checked on the host, else the generic
+//     kernel runs);
+//   * global loads of tile it+1 and the LDS fragment reads of k-group kg+1 are issued BETWEEN the
+//     16-MFMA groups of k-group kg, so that a single wave can keep its SIMD's matrix pipe busy
+//     (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles: plenty of issue slots per gap);
+//   * per-thread row offsets / validity are hoisted out of the loop.
+#pragma once
+#include "gemm_core.h"
+
+namespace regt {
+
+constexpr int G_MAX_ITERS = 96;   // descriptor table capacity (e.g. K=512 in 3 segments with region repeats)
+
+struct ItDesc {
+    const float* A;
+    const float* B0;
+    const float* B1;
+    long lda, ldb;
+    int K, k0, region, nsplit;
+};
+constexpr int G_TABLE_BYTES = G_MAX_ITERS * (int)sizeof(ItDesc);
+constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
+
+template <bool BT, bool REGION>
+struct FastCore {
+    const GemmSegs& S;
+    RowMap rm;
+    int n0, N;
+    float* lds;
+    ItDesc* table;
+    int nit;
+    int tid, lane, wr, wc;
+    long arow[4];      // global row of the thread's 4 A slots (or -1)
+    int areg[4];       // region of that row (REGION only)
+
+    __device__ __forceinline__ FastCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_)
+        : S(s), rm(r), n0(n0_), N(N_), lds(lds_) {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        const int wid = tid >> 6;
+        wr = wid >> 1;
+        wc = wid & 1;
+        table = reinterpret_cast<ItDesc*>(lds + 2 * G_STAGE);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (tid + 256 * i) >> 3;
+            arow[i] = rr < rm.nvalid ? rm.grow(rr) : -1;
+            areg[i] = 0;
+            if (REGION && arow[i] >= 0) areg[i] = S.node_region[arow[i] / S.row_div];
+        }
+    }
+
+    // Re-target the row map (candidate kernel: same tile, next period) without re-planning.
+    __device__ __forceinline__ void set_rows(RowMap r) {
+        rm = r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = (tid + 256 * i) >> 3;
+            arow[i] = rr < rm.nvalid ? rm.grow(rr) : -1;
+        }
+    }
+
+    // Build the iteration table (one thread), return its length to everybody.  Ends with a barrier.
+    __device__ __forceinline__ void plan() {
+        int rmin = 0, rmax = 0;
+        int* red = reinterpret_cast<int*>(lds);
+        if (REGION) {
+            if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
+            __syncthreads();
+            if (tid < GBM && tid < rm.nvalid) {
+                const int reg = S.node_region[rm.grow(tid) / S.row_div];
+                atomicMin(&red[0], reg);
+                atomicMax(&red[1], reg);
+            }
+            __syncthreads();
+            rmin = red[0];
+            rmax = red[1];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int n = 0;
+            for (int s = 0; s < S.nseg; ++s) {
+                const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
+                const bool reg = REGION && (g.flags & SEG_REGION);
+                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : 0;
+                for (int r = r0; r <= r1; ++r)
+                    for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
+                        ItDesc d;
+                        const long off = reg ? (long)r * g.b_region_stride : 0;
+                        d.A = g.A; d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
+                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
+                        table[n++] = d;
+                    }
+            }
+            red[2] = n;
+        }
+        __syncthreads();
+        nit = red[2];
+        __syncthreads();
+    }
+
+    __device__ __forceinline__ float4 load_a(const ItDesc& d, int i) const {
+        const int k = d.k0 + 4 * ((tid + 256 * i) & 7);
+        bool ok = arow[i] >= 0 && k < d.K;
+        if (REGION) ok = ok && (d.region < 0 || areg[i] == d.region);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4*>(d.A + arow[i] * d.lda + k);
+        return v;
+    }
+    __device__ __forceinline__ float4 load_b(const ItDesc& d, int i) const {
+        const int slot = tid + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (BT) {
+            const int n = n0 + (slot >> 3), k = d.k0 + 4 * (slot & 7);
+            if (n < N && k < d.K) {
+                const float* p = n < d.nsplit ? d.B0 + (long)n * d.ldb : d.B1 + (long)(n - d.nsplit) * d.ldb;
+                v = *reinterpret_cast<const float4*>(p + k);
+            }
+        } else {
+            const int k = d.k0 + (slot >> 5), n = n0 + 4 * (slot & 31);
+            if (k < d.K && n < N) v = *reinterpret_cast<const float4*>(d.B0 + (long)k * d.ldb + n);
+        }
+        return v;
+    }
+    __device__ __forceinline__ void store_a(float* st, int i, float4 v, bool relu) const {
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        const int slot = tid + 256 * i;
+        *reinterpret_cast<float4*>(st + (slot >> 3) * G_LDS_ROW + 4 * (slot & 7)) = v;
+    }
+    __device__ __forceinline__ void store_b(float* st, int i, float4 v) const {
+        const int slot = tid + 256 * i;
+        float* lb = st + G_A_TILE;
+        if (BT) *reinterpret_cast<float4*>(lb + (slot >> 3) * G_LDS_ROW + 4 * (slot & 7)) = v;
+        else *reinterpret_cast<float4*>(lb + (slot >> 5) * G_LDS_KROW + 4 * (slot & 31)) = v;
+    }
+    struct Frag { float4 a[2], b[2]; };
+    __device__ __forceinline__ Frag read_frag(const float* st, int kg) const {
+        const int lr = lane & 31, lh = lane >> 5;
+        Frag f;
+        const float* lb = st + G_A_TILE;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+            f.a[mi] = *reinterpret_cast<const float4*>(st + (wr * 64 + mi * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (BT) {
+                f.b[ni] = *reinterpret_cast<const float4*>(lb + (wc * 64 + ni * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
+            } else {
+                const float* q = lb + (kg * 8 + lh * 4) * G_LDS_KROW + wc * 64 + ni * 32 + lr;
+                f.b[ni] = make_float4(q[0], q[G_LDS_KROW], q[2 * G_LDS_KROW], q[3 * G_LDS_KROW]);
+            }
+        }
+        return f;
+    }
+    __device__ __forceinline__ void mfma16(const Frag& f, f32x16 (&acc)[2][2]) const {
+        const float* a0 = reinterpret_cast<const float*>(&f.a[0]);
+        const float* a1 = reinterpret_cast<const float*>(&f.a[1]);
+        const float* b0 = reinterpret_cast<const float*>(&f.b[0]);
+        const float* b1 = reinterpret_cast<const float*>(&f.b[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // acc += sum over the planned iterations.  `relu_a`: apply relu to A while staging (head).
+    __device__ __forceinline__ void run(f32x16 (&acc)[2][2], bool relu_a) const {
+        if (nit == 0) return;
+        float4 ra[4], rb[4];
+        {
+            const ItDesc d = table[0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ra[i] = load_a(d, i); rb[i] = load_b(d, i); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { store_a(lds, i, ra[i], relu_a); store_b(lds, i, rb[i]); }
+        }
+        __syncthreads();
+        Frag cur = read_frag(lds, 0);
+        for (int it = 0; it + 1 < nit; ++it) {
+            const float* st = lds + (it & 1) * G_STAGE;
+            float* nx = lds + ((it + 1) & 1) * G_STAGE;
+            const ItDesc d = table[it + 1];
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                Frag nxt;
+                if (kg < 3) nxt = read_frag(st, kg + 1);
+                ra[kg] = load_a(d, kg);
+                rb[kg] = load_b(d, kg);
+                mfma16(cur, acc);
+                if (kg < 3) cur = nxt;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { store_a(nx, i, ra[i], relu_a); store_b(nx, i, rb[i]); }
+            __syncthreads();
+            cur = read_frag(nx, 0);
+        }
+        {
+            const float* st = lds + ((nit - 1) & 1) * G_STAGE;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                Frag nxt;
+                if (kg < 3) nxt = read_frag(st, kg + 1);
+                mfma16(cur, acc);
+                if (kg < 3) cur = nxt;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- LDS-staged vector epilogue (same as GemmCore) ----------------------------------------------
+    __device__ __forceinline__ void stage(f32x16 (&acc)[2][2]) const {
+        const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    lds[(wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * G_LDS_KROW + wc * 64 + ni * 32 + lr] =
+                        acc[mi][ni][reg];
+        __syncthreads();
+    }
+    __device__ __forceinline__ int erow(int i) const { return (tid >> 5) + 8 * i; }
+    __device__ __forceinline__ int ecol() const { return n0 + 4 * (tid & 31); }
+    __device__ __forceinline__ float4 eread(int i) const {
+        return *reinterpret_cast<const float4*>(lds + erow(i) * G_LDS_KROW + 4 * (tid & 31));
+    }
+    template <class F>
+    __device__ __forceinline__ void for_each_vec(f32x16 (&acc)[2][2], const F& f) const {
+        stage(acc);
+        const int c = ecol();
+        if (c < N) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typename F::Aux aux[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = erow(4 * g + j);
+                    if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = erow(4 * g + j);
+                    if (r < rm.nvalid) f.apply(rm.grow(r), c, eread(4 * g + j), aux[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+};
+
+}  // namespace regt
