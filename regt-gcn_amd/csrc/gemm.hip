@@ -200,6 +200,8 @@ static int fast_class(const GemmSegs& S, int N, bool vec) {
         bt = b;
         if (g.flags & SEG_REGION) region = 1;
         if (g.flags & SEG_RELU_A) relu = 1;
+        if (b && g.nsplit < N && g.nsplit % GBN != 0) return -1;      // a column tile must not straddle B0 | B1
+        if (g.lda >= (1L << 22) || g.ldb >= (1L << 22)) return -1;    // 32-bit byte offsets inside a tile
         iters += (long)cdiv(g.K, GBK) * ((g.flags & SEG_REGION) ? 8 : 1);   // region repeats are bounded per tile below
     }
     if (relu && S.nseg != 1) return -1;
@@ -275,75 +277,15 @@ template <bool VEC>
 __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (a.C + GBN - 1) / GBN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int i0 = (bid / tiles_n) * GBM;
-    const int n0 = (bid % tiles_n) * GBN;
-    const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
     const long C = a.C;
     f32x16 acc[2][2];
     if constexpr (VEC) {
-        float4 oh[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) oh[i] = make_float4(0, 0, 0, 0);
-        FastCore<true, false> core(a.S, RowMap{(long)i0 * a.T, a.T, nvalid}, n0, a.C, lds);
-        core.plan();
-        for (int t = 0; t < a.T; ++t) {
-            const RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
-            core.set_rows(rm);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            core.run(acc, false);
-            core.stage(acc);
-            const float pt = a.probs[t];
-            const int c = core.ecol();
-            if (c < a.C) {
-                const float4 b = ld4(a.bias + c);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 Z[4], hv[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = core.erow(4 * g + j);
-                        if (r < nvalid) {
-                            const long m = rm.grow(r);
-                            Z[j] = ld4(a.ZR + m * 2 * C + c);
-                            hv[j] = ld4(a.h + m * C + c);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = core.erow(4 * g + j);
-                        if (r < nvalid) {
-                            const long m = rm.grow(r);
-                            const float4 v = core.eread(4 * g + j);
-#define F_(k) fast_tanh(v.k + b.k)
-                            const float4 ht = REGT_V4(F_);
-#undef F_
-                            st4(a.Ht + m * C + c, ht);
-                            float4& o = oh[4 * g + j];
-                            o.x += pt * (Z[j].x * hv[j].x + (1.0f - Z[j].x) * ht.x);
-                            o.y += pt * (Z[j].y * hv[j].y + (1.0f - Z[j].y) * ht.y);
-                            o.z += pt * (Z[j].z * hv[j].z + (1.0f - Z[j].z) * ht.z);
-                            o.w += pt * (Z[j].w * hv[j].w + (1.0f - Z[j].w) * ht.w);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        const int c = n0 + 4 * (threadIdx.x & 31);
-        if (c < a.C) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = (threadIdx.x >> 5) + 8 * i;
-                if (r < nvalid) st4(a.OH + (long)(i0 + r) * C + c, oh[i]);
-            }
-        }
+        // the vector path lives in gemm_cand_flat_kernel
     } else {
+        const int bid = xcd_remap(blockIdx.x, gridDim.x);
+        const int i0 = (bid / tiles_n) * GBM;
+        const int n0 = (bid % tiles_n) * GBN;
+        const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
         f32x16 oh[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -377,6 +319,88 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
     }
 }
 
+// Vector path of the candidate stage: a FLAT GEMM over the (node*T + t) rows, same geometry and
+// efficiency as the gate GEMM.  Rows of one node are adjacent, so the attention-weighted sum over the
+// T periods is a segmented reduction inside the 128-row tile, done in LDS after the blend; a node
+// that straddles two tiles (T <= 64 < 128, so never more than two) gets one partial sum from each,
+// added atomically into the zero-initialised hidden state -- two addends commute, so the result is
+// bit-reproducible.
+__global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const long C = a.C, M = (long)a.num_nodes * a.T;
+    const int tiles_n = (a.C + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    const RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    FastCore<true, false> core(a.S, rm, n0, a.C, lds);
+    core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    core.run(acc, false);
+    core.stage(acc);
+    const int c = core.ecol();
+    const int node0 = (int)(m0 / a.T);
+    if (c < a.C) {
+        const float4 b = ld4(a.bias + c);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 Z[4], hv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = core.erow(4 * g + j);
+                if (r < rm.nvalid) {
+                    Z[j] = ld4(a.ZR + (m0 + r) * 2 * C + c);
+                    hv[j] = ld4(a.h + (m0 + r) * C + c);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = core.erow(4 * g + j);
+                if (r < rm.nvalid) {
+                    const long m = m0 + r;
+                    const float pt = a.probs[(int)(m % a.T)];
+                    const float4 v = core.eread(4 * g + j);
+#define F_(k) fast_tanh(v.k + b.k)
+                    const float4 ht = REGT_V4(F_);
+#undef F_
+                    st4(a.Ht + m * C + c, ht);
+                    float4 o;
+                    o.x = pt * (Z[j].x * hv[j].x + (1.0f - Z[j].x) * ht.x);
+                    o.y = pt * (Z[j].y * hv[j].y + (1.0f - Z[j].y) * ht.y);
+                    o.z = pt * (Z[j].z * hv[j].z + (1.0f - Z[j].z) * ht.z);
+                    o.w = pt * (Z[j].w * hv[j].w + (1.0f - Z[j].w) * ht.w);
+                    *reinterpret_cast<float4*>(lds + r * G_LDS_KROW + 4 * (threadIdx.x & 31)) = o;   // own element
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // segmented sum over each node's rows inside the tile
+    const int node1 = (int)((m0 + rm.nvalid - 1) / a.T);
+    const int items = (node1 - node0 + 1) * 32;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int node = node0 + (it >> 5), c4 = it & 31;
+        const int cc = n0 + 4 * c4;
+        if (cc >= a.C) continue;
+        long lo = (long)node * a.T - m0, hi = lo + a.T - 1;
+        if (lo < 0) lo = 0;
+        if (hi > rm.nvalid - 1) hi = rm.nvalid - 1;
+        float4 s4 = make_float4(0, 0, 0, 0);
+        for (long r = lo; r <= hi; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * G_LDS_KROW + 4 * c4);
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        float* o = a.OH + (long)node * C + cc;
+        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+    }
+}
+
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
@@ -384,8 +408,12 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
                      fast_class(a.S, a.C, true) == 1;
     if (vec) {
         static bool attr_done = false;
-        if (int rc = set_lds_once(&gemm_cand_kernel<true>, G_FAST_LDS_BYTES, &attr_done)) return rc;
-        hipLaunchKernelGGL(gemm_cand_kernel<true>, dim3((unsigned)tiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        if (int rc = set_lds_once(&gemm_cand_flat_kernel, G_FAST_LDS_BYTES, &attr_done)) return rc;
+        const long M = (long)a.num_nodes * a.T;
+        const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
+        REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
+        REGT_CHECK_HIP(hipMemsetAsync(a.OH, 0, (size_t)a.num_nodes * a.C * sizeof(float), st));
+        hipLaunchKernelGGL(gemm_cand_flat_kernel, dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
         static bool attr_done2 = false;
         if (int rc = set_lds_once(&gemm_cand_kernel<false>, G_LDS_BYTES, &attr_done2)) return rc;
@@ -403,6 +431,164 @@ constexpr int W_LDP = 128 + 4;
 
 template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 128 ? 2 : 1;
+    constexpr int LDQ = BNW + 4;
+    constexpr int P_TILE = W_BK * W_LDP, Q_TILE = W_BK * LDQ;
+    constexpr int QSLOTS = (W_BK * BNW / 4) / 256;          // float4 slots per thread for Q (4 or 1)
+    using Core = FastCore<true, false>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = BNW == 128 ? (wid >> 1) : wid, wc = BNW == 128 ? (wid & 1) : 0;
+    const int tiles_i = (a.Nout + 127) / 128, tiles_j = (a.Nin + BNW - 1) / BNW;
+    const int tile = blockIdx.x % (tiles_i * tiles_j), chunk = blockIdx.x / (tiles_i * tiles_j);
+    const int i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * BNW;
+    long r0, r1;
+    if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
+    else { r0 = (long)chunk * a.kchunk; r1 = r0 + a.kchunk < a.M ? r0 + a.kchunk : a.M; }
+    const int nrows = (int)(r1 - r0);
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float csum = 0.f;
+
+    // Both operands stream through wave-uniform buffer descriptors based at the chunk's first row
+    // (vector path: ldp/ldq multiples of 4 and 16-B aligned bases, checked on the host).
+    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(a.P + r0 * a.ldp + i0);
+    const __amdgpu_buffer_rsrc_t sq = Core::make_srd(a.Q + r0 * a.ldq + j0);
+    const int ldp = (int)a.ldp, ldq = (int)a.ldq;
+
+    auto load = [&](int k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = tid + 256 * s;
+            const int m = k0 + (slot >> 5), i = 4 * (slot & 31);
+            const bool ok = m < nrows && i0 + i < a.Nout;
+            rp[s] = Core::srd_load(sp, ok ? 4u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
+        }
+#pragma unroll
+        for (int s = 0; s < QSLOTS; ++s) {
+            const int slot = tid + 256 * s;
+            const int m = k0 + slot / (BNW / 4), j = 4 * (slot % (BNW / 4));
+            const bool ok = m < nrows && j0 + j < a.Nin;
+            rq[s] = Core::srd_load(sq, ok ? 4u * (unsigned)(m * ldq + j) : Core::SRD_OOB);
+        }
+    };
+    auto store = [&](int stage, const float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
+        float* lp = lds + stage * (P_TILE + Q_TILE);
+        float* lq = lp + P_TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int slot = tid + 256 * s;
+            *reinterpret_cast<float4*>(lp + (slot >> 5) * W_LDP + 4 * (slot & 31)) = rp[s];
+        }
+#pragma unroll
+        for (int s = 0; s < QSLOTS; ++s) {
+            int slot = tid + 256 * s;
+            float4 v = rq[s];
+            if (a.q_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(lq + (slot / (BNW / 4)) * LDQ + 4 * (slot % (BNW / 4))) = v;
+        }
+    };
+    struct Frag { float a[WM][4], b[WN][4]; };
+    auto read_frag = [&](int stage, int kg) {
+        const float* lp = lds + stage * (P_TILE + Q_TILE);
+        const float* lq = lp + P_TILE;
+        Frag f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kg * 8 + lh * 4 + j;
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) f.a[mi][j] = lp[k * W_LDP + wr * (32 * WM) + mi * 32 + lr];
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) f.b[ni][j] = lq[k * LDQ + wc * (32 * WN) + ni * 32 + lr];
+        }
+        return f;
+    };
+    auto mfma = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    auto colsum = [&](int stage) {
+        if (a.colsum && j0 == 0 && tid < 128) {
+            const float* lp = lds + stage * (P_TILE + Q_TILE);
+#pragma unroll 8
+            for (int k = 0; k < W_BK; ++k) csum += lp[k * W_LDP + tid];
+        }
+    };
+
+    const int nit = (nrows + W_BK - 1) / W_BK;
+    if (nit > 0) {
+        float4 rp[4], rq[QSLOTS];
+        load(0, rp, rq);
+        store(0, rp, rq);
+        __syncthreads();
+        Frag cur = read_frag(0, 0);
+        for (int it = 0; it + 1 < nit; ++it) {
+            const int stage = it & 1;
+            load((it + 1) * W_BK, rp, rq);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                Frag nxt;
+                if (kg < 3) nxt = read_frag(stage, kg + 1);
+#pragma unroll
+                for (int r = 0; r < 4 * WM * WN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);   // VALU | SALU
+                }
+                mfma(cur);
+                if (kg < 3) cur = nxt;
+            }
+            colsum(stage);
+            store(stage ^ 1, rp, rq);
+            __syncthreads();
+            cur = read_frag(stage ^ 1, 0);
+        }
+        {
+            const int stage = (nit - 1) & 1;
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                Frag nxt;
+                if (kg < 3) nxt = read_frag(stage, kg + 1);
+                mfma(cur);
+                if (kg < 3) cur = nxt;
+            }
+            colsum(stage);
+        }
+    }
+    const long stride = (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0);
+    float* out = a.slab + (long)chunk * stride;
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int i = i0 + wr * (32 * WM) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (i < a.Nout) {
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) {
+                    int j = j0 + wc * (32 * WN) + ni * 32 + lr;
+                    if (j < a.Nin) out[(long)i * a.Nin + j] = acc[mi][ni][reg];
+                }
+            }
+        }
+    if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum;
+}
+
+// Generic fallback (scalar-guarded loads) for operands that are not 16-byte tileable, e.g. the (N, O) head gradient.
+template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
+__global__ __launch_bounds__(256, 2) void wgrad_kernel_generic(WgradArgs a) {
     constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 128 ? 2 : 1;
     constexpr int LDQ = BNW + 4;
     constexpr int P_TILE = W_BK * W_LDP, Q_TILE = W_BK * LDQ;
@@ -528,12 +714,21 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
     REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
     size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
+    const bool fast = a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.Nout % 4 == 0 && a.Nin % 4 == 0 && a16(a.P) && a16(a.Q) &&
+                      a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536);
     if (wide) {
-        static bool attr_done = false;
-        if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
-        hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
-    } else {
+        static bool attr_done = false, attr_done_g = false;
+        if (fast) {
+            if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
+            hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+        } else {
+            if (int rc = set_lds_once(&wgrad_kernel_generic<128>, (int)lds, &attr_done_g)) return rc;
+            hipLaunchKernelGGL(wgrad_kernel_generic<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+        }
+    } else if (fast) {
         hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(wgrad_kernel_generic<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     }
     REGT_CHECK_LAUNCH();
     return REGT_OK;

@@ -105,28 +105,56 @@ struct FastCore {
         __syncthreads();
     }
 
-    __device__ __forceinline__ float4 load_a(const ItDesc& d, int i) const {
-        const int k = d.k0 + 4 * ((tid + 256 * i) & 7);
-        bool ok = arow[i] >= 0 && k < d.K;
-        if (REGION) ok = ok && (d.region < 0 || areg[i] == d.region);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(d.A + arow[i] * d.lda + k);
-        return v;
+    // Guarded loads as raw buffer loads: the per-tile base goes into a wave-uniform buffer descriptor
+    // (SGPRs) and every lane supplies a 32-bit byte offset; a masked-out slot gets an offset beyond
+    // num_records, for which the hardware returns 0 without touching memory.  No branch, no flat
+    // address (a flat load would also count on lgkmcnt and serialise with the LDS fragment reads).
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    static constexpr unsigned SRD_RANGE = 0x7FFFFFF0u, SRD_OOB = 0x7FFFFFF8u;
+    __device__ __forceinline__ static __amdgpu_buffer_rsrc_t make_srd(const float* p) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+        return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)SRD_RANGE, 0x00020000);
     }
-    __device__ __forceinline__ float4 load_b(const ItDesc& d, int i) const {
+    __device__ __forceinline__ static float4 srd_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    struct Srds { __amdgpu_buffer_rsrc_t a, b; int lda, ldb, K, k0, region; };
+    __device__ __forceinline__ Srds make_srds(const ItDesc& d) const {
+        Srds r;
+        r.lda = __builtin_amdgcn_readfirstlane((int)d.lda);
+        r.ldb = __builtin_amdgcn_readfirstlane((int)d.ldb);
+        r.K = __builtin_amdgcn_readfirstlane(d.K);
+        r.k0 = __builtin_amdgcn_readfirstlane(d.k0);
+        r.region = __builtin_amdgcn_readfirstlane(d.region);
+        r.a = make_srd(d.A + rm.base * d.lda);
+        const int ns = __builtin_amdgcn_readfirstlane(d.nsplit);
+        if (BT) r.b = make_srd(n0 < ns ? d.B0 + (long)n0 * d.ldb : d.B1 + (long)(n0 - ns) * d.ldb);
+        else r.b = make_srd(d.B0 + n0);
+        return r;
+    }
+    __device__ __forceinline__ float4 load_a(const Srds& d, int i) const {
         const int slot = tid + 256 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = d.k0 + 4 * (slot & 7);
+        bool ok = (slot >> 3) < rm.nvalid && k < d.K;
+        if (REGION) ok = ok && (d.region < 0 || areg[i] == d.region);
+        const unsigned off = ok ? 4u * (unsigned)((slot >> 3) * (int)rm.mul * d.lda + k) : SRD_OOB;
+        return srd_load(d.a, off);
+    }
+    __device__ __forceinline__ float4 load_b(const Srds& d, int i) const {
+        const int slot = tid + 256 * i;
         if (BT) {
-            const int n = n0 + (slot >> 3), k = d.k0 + 4 * (slot & 7);
-            if (n < N && k < d.K) {
-                const float* p = n < d.nsplit ? d.B0 + (long)n * d.ldb : d.B1 + (long)(n - d.nsplit) * d.ldb;
-                v = *reinterpret_cast<const float4*>(p + k);
-            }
+            const int nl = slot >> 3, k = d.k0 + 4 * (slot & 7);
+            const bool ok = n0 + nl < N && k < d.K;
+            return srd_load(d.b, ok ? 4u * (unsigned)(nl * d.ldb + k) : SRD_OOB);
         } else {
-            const int k = d.k0 + (slot >> 5), n = n0 + 4 * (slot & 31);
-            if (k < d.K && n < N) v = *reinterpret_cast<const float4*>(d.B0 + (long)k * d.ldb + n);
+            const int k = d.k0 + (slot >> 5), nl = 4 * (slot & 31);
+            const bool ok = k < d.K && n0 + nl < N;
+            return srd_load(d.b, ok ? 4u * (unsigned)(k * d.ldb + nl) : SRD_OOB);
         }
-        return v;
     }
     __device__ __forceinline__ void store_a(float* st, int i, float4 v, bool relu) const {
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -177,7 +205,7 @@ struct FastCore {
         if (nit == 0) return;
         float4 ra[4], rb[4];
         {
-            const ItDesc d = table[0];
+            const Srds d = make_srds(table[0]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ra[i] = load_a(d, i); rb[i] = load_b(d, i); }
 #pragma unroll
@@ -188,13 +216,23 @@ struct FastCore {
         for (int it = 0; it + 1 < nit; ++it) {
             const float* st = lds + (it & 1) * G_STAGE;
             float* nx = lds + ((it + 1) & 1) * G_STAGE;
-            const ItDesc d = table[it + 1];
+            const Srds d = make_srds(table[it + 1]);
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
                 Frag nxt;
                 if (kg < 3) nxt = read_frag(st, kg + 1);
                 ra[kg] = load_a(d, kg);
                 rb[kg] = load_b(d, kg);
+                // Keep this group's global loads / LDS reads ahead of its MFMAs (hipcc otherwise sinks the
+                // loads to their use at the end of the iteration and exposes the HBM latency) and spread
+                // them over the first MFMA gaps: 1 MFMA, then one memory op and a few VALU, repeated.
+#pragma unroll
+                for (int r = 0; r < 10; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // VALU | SALU
+                }
                 mfma16(cur, acc);
                 if (kg < 3) cur = nxt;
             }

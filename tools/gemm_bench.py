@@ -23,7 +23,9 @@ def timeit(fn, n=10):
 
 def main():
     R.load_library()
-    shapes = [(1_200_000, 256, 512), (1_200_000, 256, 256), (300_000, 256, 512), (1_200_000, 64, 256), (100_000, 256, 128)]
+    shapes = [(1_200_000, 256, 512), (1_200_000, 256, 256), (150_000, 2048, 512), (75_000, 4096, 512), (1_200_000, 64, 256), (100_000, 256, 128)]
+    if len(sys.argv) > 1:
+        shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
     for m, k, n in shapes:
         a = torch.randn(m, k, device="cuda")
         w = torch.randn(n, k, device="cuda") / 16
