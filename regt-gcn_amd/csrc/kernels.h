@@ -100,7 +100,7 @@ int graph_fingerprint(const int64_t* ei, const float* w, long E, unsigned long l
 // ---- sparse aggregation ------------------------------------------------------------------------
 int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st);            // (N,F,T) -> (N,T,F)
 int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const float* X, float* Y,
-                    int nrows, int nrows_x, int W, hipStream_t st);                              // Y[r] = sum val*X[col]
+                    int nrows, int nrows_x, int W, int nstack, hipStream_t st);                  // Y[r] = sum val*X[col]; rows = nstack x nodes
 
 // ---- cell backward head / small element-wise kernels -------------------------------------------
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);

@@ -97,6 +97,64 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ r
     }
 }
 
+// ---- XCD-aware column-panel variant (large graphs) --------------------------------------------------
+// The plain kernel above re-reads every neighbour row from the Infinity Cache: X (N*W*4 B, 154 MB at
+// cfg-3) does not fit the 4 MiB L2 of an XCD, so the gather traffic is nnz*W*4 B (3.1 GB) and the
+// kernel runs at the cache-fabric rate, not at the HBM rate.  Here the row is cut into 128-byte column
+// panels (one cache line per neighbour per panel) and the work is laid out so that ALL workgroups
+// resident on one XCD work on the same (node chunk, panel) at the same time: workgroup b lands on XCD
+// b % 8 (round-robin dispatch -- used for speed only), XCD x owns the contiguous node chunk x (with
+// region-contiguous node ids that is ~one region, whose neighbours are mostly inside the chunk) and
+// walks panel 0, 1, ... over that chunk.  The live working set per XCD is chunk_nodes * 128 B
+// (1.6 MB at cfg-3) and stays in L2, so each X line is fetched from HBM / MALL about once.
+// Eight lanes own one (row, panel): 8 x 16 B = one 128-B line per neighbour; the 8 lanes pull 8
+// (col, val) pairs with one coalesced load and broadcast them by shuffle, four gathers in flight.
+__global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                         const float* __restrict__ val, const float* __restrict__ X,
+                                                         float* __restrict__ Y, int nnodes, int nstack, int W4,
+                                                         int npanels, int nrb) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int per_panel = nstack * nrb;
+    const int panel = li / per_panel;
+    if (panel >= npanels) return;
+    const int rem = li - panel * per_panel;
+    const int s = rem / nrb, rb = rem - s * nrb;
+    const int q = nnodes / 8, r8 = nnodes % 8;
+    const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int csz = q + (xcd < r8 ? 1 : 0);
+    const int g = threadIdx.x >> 3, gl = threadIdx.x & 7;
+    if (rb * 32 + g >= csz) return;                       // whole 8-lane group leaves together
+    const long row = (long)s * nnodes + c0 + rb * 32 + g;
+    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * 8 + gl;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int base = beg; base < end; base += 8) {
+        const int n = end - base < 8 ? end - base : 8;
+        int myc = 0;
+        float myv = 0.f;
+        if (gl < n) { myc = col[base + gl]; myv = val[base + gl]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h * 4 < n) {
+                float4 x[4];
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {               // lanes >= n carry (col 0, val 0): harmless
+                    const int c = __shfl(myc, h * 4 + e, 8);
+                    v[e] = __shfl(myv, h * 4 + e, 8);
+                    x[e] = X4[(long)c * W4];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc.x = fmaf(v[e], x[e].x, acc.x); acc.y = fmaf(v[e], x[e].y, acc.y);
+                    acc.z = fmaf(v[e], x[e].z, acc.z); acc.w = fmaf(v[e], x[e].w, acc.w);
+                }
+            }
+        }
+    }
+    reinterpret_cast<float4*>(Y)[row * W4 + panel * 8 + gl] = acc;
+}
+
 template <int G, int CH>
 static int launch_spmm_t(const int* rowptr, const int* col, const float* val, const float* X, float* Y, int nrows,
                          int nrows_x, int W4, hipStream_t st) {
@@ -110,11 +168,23 @@ static int launch_spmm_t(const int* rowptr, const int* col, const float* val, co
 }
 
 int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const float* X, float* Y, int nrows,
-                    int nrows_x, int W, hipStream_t st) {
+                    int nrows_x, int W, int nstack, hipStream_t st) {
     REGT_CHECK_ARG(nrows > 0 && W > 0, "spmm: empty problem");
     REGT_CHECK_ARG(W % 4 == 0, "spmm: row width %d must be a multiple of 4 floats", W);
     REGT_CHECK_ARG(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0, "spmm: X/Y must be 16-B aligned");
+    REGT_CHECK_ARG(nstack >= 1 && nrows % nstack == 0, "spmm: nrows=%d not a multiple of nstack=%d", nrows, nstack);
     const int W4 = W / 4;
+    // Panel variant when the X matrix cannot live in the XCDs' L2s anyway and rows are whole cache lines.
+    if (W4 % 8 == 0 && (long)nrows_x * W * 4 > (24L << 20) && nrows / nstack >= 4096) {
+        const int nnodes = nrows / nstack, npanels = W4 / 8;
+        const int nrb = cdiv(cdiv(nnodes, 8), 32);
+        const long grid = 8L * npanels * nstack * nrb;
+        REGT_CHECK_ARG(grid < (1L << 31), "spmm: grid too large");
+        hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, X, Y, nnodes, nstack, W4,
+                           npanels, nrb);
+        REGT_CHECK_LAUNCH();
+        return REGT_OK;
+    }
 #define REGT_SPMM(G, CH) return launch_spmm_t<G, CH>(rowptr, col, val, X, Y, nrows, nrows_x, W4, st)
     if (W4 <= 8) REGT_SPMM(8, 1);
     if (W4 <= 16) REGT_SPMM(16, 1);

@@ -91,6 +91,20 @@ def test_spmm_matches_oracle(R, width):
     assert float((got.double() - want64).abs().max()) < 5e-6
 
 
+def test_spmm_panel_variant_large_graph(R):
+    """Large enough (X > 24 MB, width a multiple of 32) to take the XCD-aware column-panel kernel."""
+    n, e, width = 41003, 300000, 160
+    ei, w = _rand_graph(n, e, 9)
+    rp, col, val = R.graph.gcn_csr(ei.cuda(), w.cuda(), n)
+    x = torch.randn(n, width)
+    got = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
+    s, d, wn = G.gcn_norm_edges(ei, w, n, torch.float32)
+    want = G.propagate(s, d, wn, x, n)
+    assert float((got - want).abs().max()) < 2e-6
+    again = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
+    assert torch.equal(got, again)
+
+
 def test_spmm_empty_rows_and_hub(R):
     # node 0 receives every edge (hub), nodes 5.. receive none
     n = 300
