@@ -120,7 +120,7 @@ def main():
     g = R.data.synthetic_regional_graph(gnodes, gedges, gregions, seed=42)
     C = R.nn.HIDDEN
     torch.manual_seed(42)                     # same random-init weights on every rank (run.py:71)
-    model = R.RegionalTemporalGCN(node_features=F, num_nodes=nodes, periods=T, output_dim=O, num_regions=regions)
+    model = R.RegionalTemporalGCN(node_features=F, num_nodes=nodes, periods=T, output_dim=O, num_regions=gregions)
     model = model.to(dev)
     n_snap = 4
     snaps = R.data.synthetic_snapshots(gnodes, F, T, O, n_snap, seed=42)

@@ -142,10 +142,12 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     loc_w = [region_attr[r].to(device) for r in mine]
     n_loc = hi - lo
     w_all = [cheb_edge_weights(ei, ew, n_loc) for ei, ew in zip(loc_idx, loc_w)]
-    owner = node_regions([t.cpu() for t in loc_idx], n_loc)
+    # region ids stay GLOBAL: the region linear layer (tgnn.linear, (C, R_global*C)) is replicated on
+    # every rank and its blocks are addressed by global region id
+    owner = np.asarray(mine, dtype=np.int32)[node_regions([t.cpu() for t in loc_idx], n_loc)]
     rp_l, col_l, val_l = raw_csr(torch.cat(loc_idx, dim=1), torch.cat(w_all), n_loc)
     nnz_a = int(col_a.numel())
-    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(mine),
+    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(region_index),
                           rowptr=torch.cat([rp_a, rp_l[1:] + nnz_a]).contiguous(),
                           col=torch.cat([col_a, col_l]).contiguous(), val=torch.cat([val_a, val_l]).contiguous(),
                           node_region=torch.from_numpy(owner).to(device), node_region_host=owner,

@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/regtgcn.h declares;
+host-side argument validation works without touching a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import regtgcn_amd as R
+from regtgcn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "regtgcn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(regt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = R.load_library()
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/regtgcn.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in _lib.SIGNATURES"
+    assert sorted(_lib.SIGNATURES) == names
+    assert lib.regt_abi_version() == _lib.ABI_VERSION
+
+
+def test_host_side_validation_without_gpu():
+    lib = R.load_library()
+    d = _lib.Dims(10, 6, 7, 256, 5, 1, 128, 1, 0.01)            # F = 7 is not a multiple of 4
+    assert lib.regt_workspace_bytes(ctypes.byref(d), 1) == 0
+    assert b"multiple of 4" in lib.regt_last_error()
+    d = _lib.Dims(104, 6, 8, 256, 5, 1, 128, 1, 0.01)
+    assert lib.regt_workspace_bytes(ctypes.byref(d), 1) > 104 * 6 * 256 * 4 * 9
+    rc = lib.regt_spmm_csr(None, None, None, None, None, 1, 1, 4, None)
+    assert rc != 0 and b"NULL" in lib.regt_last_error()
+    assert lib.regt_graph_workspace_bytes(1000, 100) > 0
+    assert lib.regt_wgrad_slab_floats(1000, 256, 256, 1) >= 256 * 256 + 256
+
+
+def test_modules_refuse_cpu_tensors_and_keep_reference_layout():
+    m = R.RegionalTemporalGCN(node_features=8, num_nodes=104, periods=6, output_dim=1)
+    sd = torch.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_in6_out1_epoch50.pt"), map_location="cpu", weights_only=True)
+    assert list(sd.keys()) == list(m.state_dict().keys())
+    assert all(tuple(sd[k].shape) == tuple(v.shape) for k, v in m.state_dict().items())
+    m.load_state_dict(sd, strict=True)
+    with pytest.raises(R.RegtError):
+        m(torch.zeros(104, 8, 6), torch.zeros(2, 0, dtype=torch.long))
+    t = R.TemporalGCN(node_features=8, periods=6, output_dim=3)
+    assert "tgnn.linear.weight" in t.state_dict() and tuple(t.state_dict()["tgnn.linear.weight"].shape) == (256, 64)
+    assert not any(k.startswith("tgnn._weight_att") for k in t.state_dict())
+    import inspect
+    assert list(inspect.signature(t.forward).parameters) == ["x", "edge_index", "edge_attr"]   # keyword call, run.py:188

@@ -171,6 +171,46 @@ def test_hidden_gradient_path(R, tpims):
         np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
 
 
+def test_region_sharded_path_matches_single_gpu(R):
+    """Two region shards executed one after the other on the one GPU (halo rows copied by hand instead of
+    all-gathered): predictions, hidden rows and the summed gradients equal the unsharded run."""
+    import numpy as np
+    world, n_per, regions_per, f, t, o = 2, 1500, 3, 8, 6, 2
+    n = n_per * world
+    g = R.data.synthetic_regional_graph(n, 12000 * world, regions_per * world, seed=5, p_intra=0.85)
+    (x, y), = R.data.synthetic_snapshots(n, f, t, o, 1, seed=5)
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions_per * world, seed=6)
+
+    def fresh():
+        m = R.RegionalTemporalGCN(f, n, t, o, num_regions=regions_per * world)
+        m.load_state_dict(p)
+        return m.cuda()
+
+    full = fresh()
+    pred_f, hid_f = full(x.cuda(), g.edge_index.cuda(), [i.cuda() for i in g.region_index], [a.cuda() for a in g.region_attr])
+    (((pred_f - y.cuda()) ** 2).sum() / (n * o)).backward()
+    shard_model = fresh()
+    bounds = np.arange(world + 1, dtype=np.int64) * n_per
+    region_owner = [r // regions_per for r in range(regions_per * world)]
+    xp_glob = R.ops.pack_x(x.cuda()).view(n, t * f)
+    for rank in range(world):
+        sh = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, n, bounds, region_owner, rank, world, "cuda")
+        lo, hi = sh.topo.node_lo, sh.topo.node_hi
+        xp = torch.zeros(sh.topo.x_rows, t * f, device="cuda")
+        xp[:n_per] = xp_glob[lo:hi]
+        for r, b in enumerate(sh.topo.boundary):
+            xp[n_per + r * sh.topo.max_boundary: n_per + r * sh.topo.max_boundary + b.size] = xp_glob[torch.from_numpy(b).cuda()]
+        pred, hid = shard_model.forward_packed(xp.view(sh.topo.x_rows, t, f), sh.graph)
+        assert float((pred - pred_f[lo:hi]).abs().max()) < 1e-6
+        assert float((hid - hid_f[lo:hi]).abs().max()) < 1e-6
+        (((pred - y[lo:hi].cuda()) ** 2).sum() / (n * o)).backward()          # grads accumulate = all-reduce(sum)
+    for (k, a), (_, b) in zip(full.named_parameters(), shard_model.named_parameters()):
+        if a.grad is None:
+            assert b.grad is None
+            continue
+        np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), atol=2e-6, rtol=1e-4, err_msg=k)
+
+
 def test_cpu_tensors_are_refused(R):
     mod = R.RegionalTemporalGCN(8, 10, 6, 1)
     with pytest.raises(R.RegtError):
