@@ -1,0 +1,107 @@
+"""run.py counterpart: the reference's training / evaluation loop semantics around the HIP hot path.
+
+Kept from the reference (run.py:163-243):
+* train(): one forward + ``mean((out - y)**2)`` + ``backward()`` per snapshot, gradients ACCUMULATE over all
+  train snapshots, ``optimizer.step()`` + ``zero_grad()`` ONCE per epoch, returns the LAST snapshot's loss;
+* test(): ``(sqrt(mean(se)), mean(se))`` over all test snapshots (the reference prints the second as "MAE");
+* RMSprop(lr, weight_decay) (run.py:145); ``range(epochs + 1)`` epochs; state_dict saved every 10 epochs
+  as ``model_in{T}_out{O}_epoch{k}.pt`` (run.py:242-243).
+Changed on purpose: snapshots and the static graph live on the GPU for the whole run (the reference copies
+every batch host->device and syncs on ``.cpu()`` every step, run.py:172,180), and the graph is prepared once.
+
+    python -m regtgcn_amd.train --model RegionalTemporalGCN --num_timesteps_in 6 --num_timesteps_out 1 \
+        --tr 0.2 --epochs 5 --fixture tests/golden/tpims_fixture.npz
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import nn as rnn
+from .data import snapshot_windows
+from .dist import allreduce_gradients
+
+REGIONS = ("IA", "KS", "KY", "OH", "WI")
+
+
+def train_epoch(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], graph, optimizer) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """One epoch of run.py::train() on device-resident snapshots; returns (last loss, all losses) as device scalars."""
+    model.train()
+    losses = []
+    for x, y in zip(xs, ys):
+        out, _ = model.forward_prepared(x, graph)
+        loss = torch.mean((out - y) ** 2)
+        loss.backward()
+        losses.append(loss.detach())
+    allreduce_gradients(list(model.parameters()))
+    optimizer.step()
+    optimizer.zero_grad()
+    return losses[-1], losses
+
+
+@torch.no_grad()
+def evaluate(model, xs, ys, graph) -> Tuple[float, float]:
+    """run.py::test(): (rmse, mse)."""
+    model.eval()
+    se = [(model.forward_prepared(x, graph)[0] - y) ** 2 for x, y in zip(xs, ys)]
+    m = torch.cat(se, dim=0).mean()
+    return float(m.sqrt()), float(m)
+
+
+def split(xs, ys, ratio: float):
+    k = int(ratio * len(xs))          # temporal_signal_split: first int(ratio*n) snapshots train, rest test
+    return (xs[:k], ys[:k]), (xs[k:], ys[k:])
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="RegT-GCN training loop (reference run.py flags)")
+    ap.add_argument("--seed", default=42, type=int)
+    ap.add_argument("--epochs", default=30, type=int)
+    ap.add_argument("--lr", default=1e-3, type=float)
+    ap.add_argument("--decay", default=1e-4, type=float)
+    ap.add_argument("--tr", "--train_ratio", default=0.8, type=float, dest="tr")
+    ap.add_argument("--num_timesteps_in", default=8, type=int)
+    ap.add_argument("--num_timesteps_out", default=4, type=int)
+    ap.add_argument("--model", default="RegionalTemporalGCN", choices=["RegionalTemporalGCN", "TemporalGCN"])
+    ap.add_argument("--fixture", required=True, help=".npz with node_data (N,F,steps), edge_index, edge_attr, edge_<R>_index/attr")
+    ap.add_argument("--out_dir", default="pretrained")
+    ap.add_argument("--is_pretrained", action="store_true")
+    ap.add_argument("--pretrained_model", default="")
+    ap.add_argument("--pretrained_model_epoch", default="0")
+    a = ap.parse_args(argv)
+    torch.manual_seed(a.seed)
+    dev = torch.device("cuda:0")
+    d = np.load(a.fixture)
+    node_data = torch.from_numpy(d["node_data"])
+    n, f = node_data.shape[:2]
+    xs, ys = snapshot_windows(node_data, a.num_timesteps_in, a.num_timesteps_out)
+    xs, ys = [x.to(dev) for x in xs], [y.to(dev) for y in ys]
+    (tx, ty), (vx, vy) = split(xs, ys, a.tr)
+    ei = torch.from_numpy(d["edge_index"]).to(dev)
+    if a.model == "RegionalTemporalGCN":
+        model = rnn.RegionalTemporalGCN(f, n, a.num_timesteps_in, a.num_timesteps_out).to(dev)
+        graph = model.prepare_graph(ei, [torch.from_numpy(d[f"edge_{r}_index"]).to(dev) for r in REGIONS],
+                                    [torch.from_numpy(d[f"edge_{r}_attr"]).to(dev) for r in REGIONS])
+    else:
+        model = rnn.TemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
+        graph = model.prepare_graph(ei, torch.from_numpy(d["edge_attr"]).to(dev), n)
+    if a.is_pretrained:
+        model.load_state_dict(torch.load(a.pretrained_model, map_location=dev, weights_only=True))
+    opt = torch.optim.RMSprop(model.parameters(), lr=a.lr, weight_decay=a.decay)
+    out_dir = os.path.join(a.out_dir, a.model)
+    os.makedirs(out_dir, exist_ok=True)
+    for epoch in range(a.epochs + 1):
+        last, _ = train_epoch(model, tx, ty, graph, opt)
+        rmse, mse = evaluate(model, vx, vy, graph)
+        print("Train Loss: {:.4f}, Test RMSE: {:.4f}, MAE: {:.4f}".format(float(last), rmse, mse))   # run.py:236 format
+        if epoch % 10 == 0:
+            torch.save(model.state_dict(), os.path.join(out_dir, "model_in{}_out{}_epoch{}.pt".format(
+                a.num_timesteps_in, a.num_timesteps_out, int(a.pretrained_model_epoch) + epoch)))
+
+
+if __name__ == "__main__":
+    main()

@@ -211,6 +211,35 @@ def test_region_sharded_path_matches_single_gpu(R):
         np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), atol=2e-6, rtol=1e-4, err_msg=k)
 
 
+def test_training_loop_matches_reference_trajectory(R, tpims):
+    """run.py semantics (accumulate over snapshots, one RMSprop step per epoch, (rmse, mse) test) driven through the
+    HIP module reproduce the trajectory recorded from the reference's own module (golden_loop.npz)."""
+    g = load_npz("golden_loop.npz")
+    t_in, t_out = int(g["t_in"]), int(g["t_out"])
+    n_train, n_test, epochs = int(g["n_train"]), int(g["n_test"]), int(g["epochs"])
+    n = tpims["node_data"].shape[0]
+    mod = R.RegionalTemporalGCN(8, n, t_in, t_out)
+    mod.load_state_dict(M.init_params("RegionalTemporalGCN", 8, t_in, t_out, num_nodes=n, seed=int(g["seed"])))
+    mod = mod.cuda()
+    ri, rw = region_lists(tpims)
+    graph = mod.prepare_graph(tpims["edge_index"].cuda(), _cuda_list(ri), _cuda_list(rw))
+    xs, ys = R.data.snapshot_windows(tpims["node_data"][:, :, :t_in + t_out + n_train + n_test - 1], t_in, t_out)
+    xs, ys = _cuda_list(xs), _cuda_list(ys)
+    opt = torch.optim.RMSprop(mod.parameters(), lr=1e-3, weight_decay=1e-4)
+    names = [str(s) for s in g["names"]]
+    losses, metrics = [], []
+    for ep in range(epochs):
+        last, all_l = R.train.train_epoch(mod, xs[:n_train], ys[:n_train], graph, opt)
+        losses += [float(v) for v in all_l]
+        assert float(last) == losses[-1]
+        metrics.append(R.train.evaluate(mod, xs[n_train:], ys[n_train:], graph))
+        named = dict(mod.named_parameters())
+        sums = [float(named[k].detach().double().sum()) for k in names]
+        np.testing.assert_allclose(sums, g["param_sums"][ep], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(losses, g["losses"], atol=1e-5)
+    np.testing.assert_allclose(np.array(metrics), g["metrics"], atol=1e-5)
+
+
 def test_cpu_tensors_are_refused(R):
     mod = R.RegionalTemporalGCN(8, 10, 6, 1)
     with pytest.raises(R.RegtError):
