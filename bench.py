@@ -170,6 +170,7 @@ def main():
     if args.warmup:
         epoch_end()
     fence()
+    alloc0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     profile = not args.no_profile
     if profile:
         lib.regt_profile_enable(1)
@@ -204,7 +205,8 @@ def main():
                                    "snapshot, RMSprop step once per K steps (run.py semantics)",
                        "global_nodes": gnodes, "global_edges": gedges, "global_regions": gregions,
                        "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: boundary-row all-gather/step + 1 grad all-reduce",
-                       "final_loss": final_loss},
+                       "final_loss": final_loss,
+                       "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0},
         }
         if stages:
             per = {k: {"launches": c, "avg_ms": ms / c} for k, (c, ms) in stages.items()}
@@ -219,11 +221,13 @@ def main():
             if "spmm" in stages:
                 c, ms = stages["spmm"]
                 W = T * F
-                nnz = int(graph.col.numel())
+                dual = graph.m_rowptr is not None and W % 32 == 0
+                nnz = int(graph.m_col.numel()) if dual else int(graph.col.numel())
                 x_rows = nodes if shard is None else shard.topo.x_rows
-                algo = x_rows * W * 4 + nnz * 8 + (2 * nodes + 1) * 4 + 2 * nodes * W * 4
+                # read X once + CSR entries (col + 1 or 2 weights) + rowptr + write both outputs
+                algo = x_rows * W * 4 + nnz * (12 if dual else 8) + (nodes + 1) * 4 * (1 if dual else 2) + 2 * nodes * W * 4
                 gbs = algo / (ms / c * 1e-3) / 1e9
-                out["roofline_spmm"] = {"kernel": "spmm_csr (stacked [A_hat; L~] x, width T*F)", "bound": "hbm", "achieved": gbs,
+                out["roofline_spmm"] = {"kernel": "spmm_dual_panel (A_hat x and L~ x in one gather pass, width T*F)" if dual else "spmm_csr (stacked [A_hat; L~] x, width T*F)", "bound": "hbm", "achieved": gbs,
                                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
                                         "avg_ms": ms / c, "bytes_per_launch": algo}
             gemm_ms = sum(ms for k, (c, ms) in stages.items() if stage_flops(k, M, C, F))

@@ -71,6 +71,10 @@ int32_t regt_graph_fingerprint(const int64_t* edge_index, const float* edge_weig
 int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
                       int32_t nrows, int32_t nrows_x, int32_t width, regt_stream_t stream);
 
+/* Both operators in one pass over a merged CSR (two weights per entry): YA = A x, YL = L x; width % 32 == 0. */
+int32_t regt_spmm_dual(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const float* X,
+                       float* YA, float* YL, int32_t num_nodes, int32_t width, regt_stream_t stream);
+
 /* Snapshot layout change (N,F,T) time-innermost (load_dataset.py:451-457) -> (N,T,F) rows. */
 int32_t regt_pack_x(const float* x, float* x_packed, int32_t num_nodes, int32_t num_features, int32_t periods,
                     regt_stream_t stream);
@@ -114,6 +118,13 @@ typedef struct regt_graph {
     const int32_t* chunk_tab;     /* (n_chunks, 2) */
     const int32_t* chunk_region;  /* (n_chunks) */
     int32_t n_chunks;
+    /* optional merged operator (N rows): one entry per distinct (row, col) of the two halves above with the
+     * A_hat weight and the L~ weight side by side; when present (and T*F % 32 == 0) both aggregations are
+     * produced by ONE gather pass.  All four NULL = not provided. */
+    const int32_t* m_rowptr;      /* (N+1) */
+    const int32_t* m_col;
+    const float* m_val_a;
+    const float* m_val_l;
 } regt_graph;
 
 typedef struct regt_params {

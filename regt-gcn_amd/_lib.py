@@ -29,7 +29,8 @@ class Dims(C.Structure):
 
 class Graph(C.Structure):
     _fields_ = [("rowptr", vp), ("col", vp), ("val", vp), ("node_region", vp), ("chunk_tab", vp),
-                ("chunk_region", vp), ("n_chunks", C.c_int32)]
+                ("chunk_region", vp), ("n_chunks", C.c_int32),
+                ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp)]
 
 
 _PARAM_FIELDS = [("attention", vp), ("conv_lin_w", vp * 3), ("conv_bias", vp * 3), ("gate_w", vp * 3),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "regt_raw_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_graph_fingerprint": (C.c_int32, [vp, vp, C.c_int64, vp, vp]),
     "regt_spmm_csr": (C.c_int32, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_spmm_dual": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp]),
     "regt_pack_x": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
     "regt_linear": (C.c_int32, [vp, C.c_int64, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, vp, C.c_int32,
                                 C.c_float, vp, C.c_int64, vp]),

@@ -203,7 +203,10 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     }
     {
         PROF("spmm", st);
-        TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, 2, st));
+        if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
+            TRY(launch_spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, T * F, st));
+        else
+            TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, 2, st));
     }
     const float* A0 = d.regional ? L.A0 : p.cheb_w0;
     const float* Aall = d.regional ? L.Aall : p.cheb_w1;
@@ -447,6 +450,12 @@ int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* va
                       int32_t nrows_x, int32_t width, regt_stream_t st) {
     REGT_CHECK_ARG(rowptr && col && val && X && Y, "regt_spmm_csr: NULL pointer");
     return launch_spmm_csr(rowptr, col, val, X, Y, nrows, nrows_x, width, 1, (hipStream_t)st);
+}
+
+int32_t regt_spmm_dual(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const float* X,
+                       float* YA, float* YL, int32_t N, int32_t width, regt_stream_t st) {
+    REGT_CHECK_ARG(rowptr && col && val_a && val_l && X && YA && YL, "regt_spmm_dual: NULL pointer");
+    return launch_spmm_dual(rowptr, col, val_a, val_l, X, YA, YL, N, width, (hipStream_t)st);
 }
 
 int32_t regt_pack_x(const float* x, float* xp, int32_t N, int32_t F, int32_t T, regt_stream_t st) {

@@ -102,6 +102,9 @@ int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st
 int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const float* X, float* Y,
                     int nrows, int nrows_x, int W, int nstack, hipStream_t st);                  // Y[r] = sum val*X[col]; rows = nstack x nodes
 
+int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
+                     float* YL, int nnodes, int W, hipStream_t st);   // YA = A x, YL = L x from one merged CSR (two weights/entry)
+
 // ---- cell backward head / small element-wise kernels -------------------------------------------
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {

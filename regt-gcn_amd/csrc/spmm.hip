@@ -155,6 +155,71 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
     reinterpret_cast<float4*>(Y)[row * W4 + panel * 8 + gl] = acc;
 }
 
+// ---- dual-operator panel variant ----------------------------------------------------------------------
+// The regional Laplacian rows are (almost) a subset of the full-graph rows: the same neighbour row
+// x[col] feeds both A_hat x and L~ x.  With a merged CSR that carries two weights per entry, one gather
+// serves both outputs -- half the gather volume of the stacked operator.  Same XCD/panel schedule as above.
+__global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                              const float* __restrict__ val_a, const float* __restrict__ val_l,
+                                                              const float* __restrict__ X, float* __restrict__ YA,
+                                                              float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb) {
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int panel = li / nrb;
+    if (panel >= npanels) return;
+    const int rb = li - panel * nrb;
+    const int q = nnodes / 8, r8 = nnodes % 8;
+    const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int csz = q + (xcd < r8 ? 1 : 0);
+    const int g = threadIdx.x >> 3, gl = threadIdx.x & 7;
+    if (rb * 32 + g >= csz) return;
+    const long row = c0 + rb * 32 + g;
+    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * 8 + gl;
+    float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), al = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int base = beg; base < end; base += 8) {
+        const int n = end - base < 8 ? end - base : 8;
+        int myc = 0;
+        float mya = 0.f, myl = 0.f;
+        if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h * 4 < n) {
+                float4 x[4];
+                float va[4], vl[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = __shfl(myc, h * 4 + e, 8);
+                    va[e] = __shfl(mya, h * 4 + e, 8);
+                    vl[e] = __shfl(myl, h * 4 + e, 8);
+                    x[e] = X4[(long)c * W4];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    aa.x = fmaf(va[e], x[e].x, aa.x); aa.y = fmaf(va[e], x[e].y, aa.y);
+                    aa.z = fmaf(va[e], x[e].z, aa.z); aa.w = fmaf(va[e], x[e].w, aa.w);
+                    al.x = fmaf(vl[e], x[e].x, al.x); al.y = fmaf(vl[e], x[e].y, al.y);
+                    al.z = fmaf(vl[e], x[e].z, al.z); al.w = fmaf(vl[e], x[e].w, al.w);
+                }
+            }
+        }
+    }
+    reinterpret_cast<float4*>(YA)[row * W4 + panel * 8 + gl] = aa;
+    reinterpret_cast<float4*>(YL)[row * W4 + panel * 8 + gl] = al;
+}
+
+int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
+                     float* YL, int nnodes, int W, hipStream_t st) {
+    REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 32 == 0, "spmm_dual: width %d must be a multiple of 32 floats", W);
+    const int W4 = W / 4, npanels = W4 / 8;
+    const int nrb = cdiv(cdiv(nnodes, 8), 32);
+    const long grid = 8L * npanels * nrb;
+    REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual: grid too large");
+    hipLaunchKernelGGL(spmm_dual_panel_kernel, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL, nnodes,
+                       W4, npanels, nrb);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 template <int G, int CH>
 static int launch_spmm_t(const int* rowptr, const int* col, const float* val, const float* X, float* Y, int nrows,
                          int nrows_x, int W4, hipStream_t st) {

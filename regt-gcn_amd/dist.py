@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .graph import PreparedGraph, cheb_edge_weights, gcn_csr, node_regions, raw_csr
+from .graph import PreparedGraph, cheb_edge_weights, gcn_csr, merge_operators, node_regions, raw_csr
 
 
 @dataclass
@@ -147,7 +147,8 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     owner = np.asarray(mine, dtype=np.int32)[node_regions([t.cpu() for t in loc_idx], n_loc)]
     rp_l, col_l, val_l = raw_csr(torch.cat(loc_idx, dim=1), torch.cat(w_all), n_loc)
     nnz_a = int(col_a.numel())
-    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(region_index),
+    m = merge_operators(rp_a, col_a, val_a, rp_l, col_l, val_l, n_loc)
+    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(region_index), m_rowptr=m[0], m_col=m[1], m_val_a=m[2], m_val_l=m[3],
                           rowptr=torch.cat([rp_a, rp_l[1:] + nnz_a]).contiguous(),
                           col=torch.cat([col_a, col_l]).contiguous(), val=torch.cat([val_a, val_l]).contiguous(),
                           node_region=torch.from_numpy(owner).to(device), node_region_host=owner,

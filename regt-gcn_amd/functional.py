@@ -53,12 +53,51 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _WorkspacePool:
+    """The forward leaves its activations in a multi-GB workspace that the backward reads.  Blocks are recycled
+    here (keyed by device and size) instead of going back to the allocator after every step: a step then never
+    depends on allocator behaviour for its one large buffer, and two forwards in flight simply use two blocks."""
+
+    def __init__(self):
+        self._free = {}
+
+    def acquire(self, nbytes: int, device) -> torch.Tensor:
+        lst = self._free.get((device, nbytes))
+        if lst:
+            return lst.pop()
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def release(self, ws: torch.Tensor):
+        lst = self._free.setdefault((ws.device, ws.numel()), [])
+        if len(lst) < 2:
+            lst.append(ws)
+
+
+_POOL = _WorkspacePool()
+
+
+class _WsHandle:
+    """Returns the block to the pool when the autograd node that owns it goes away."""
+
+    def __init__(self, ws):
+        self.ws = ws
+
+    def __del__(self):
+        try:
+            _POOL.release(self.ws)
+        except Exception:  # interpreter shutdown
+            pass
+
+
 def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
     tab, reg, n = graph.chunks_for(periods)
     g = _lib.Graph()
     g.rowptr, g.col, g.val = graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.val.data_ptr()
     g.node_region = graph.node_region.data_ptr()
     g.chunk_tab, g.chunk_region, g.n_chunks = tab.data_ptr(), reg.data_ptr(), n
+    if graph.m_rowptr is not None:
+        g.m_rowptr, g.m_col = graph.m_rowptr.data_ptr(), graph.m_col.data_ptr()
+        g.m_val_a, g.m_val_l = graph.m_val_a.data_ptr(), graph.m_val_l.data_ptr()
     return g
 
 
@@ -112,7 +151,8 @@ class RegTGCNFunction(torch.autograd.Function):
         wsb = lib.regt_workspace_bytes(C.byref(dims), gs.n_chunks)
         if wsb == 0:
             _lib.check(1, "regt_workspace_bytes")
-        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        handle = _WsHandle(_POOL.acquire(wsb, x.device))
+        ws = handle.ws
         pred = torch.empty(N, O, dtype=torch.float32, device=x.device)
         hidden = torch.empty(N, Cdim, dtype=torch.float32, device=x.device)
         ps = _fill(_lib.Params(), tens, regional)
@@ -123,6 +163,7 @@ class RegTGCNFunction(torch.autograd.Function):
             _lib.check(lib.regt_forward(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), _lib.ptr(pred),
                                         _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward")
         ctx.graph, ctx.regional, ctx.dims, ctx.ws, ctx.wsb = graph, regional, dims, ws, wsb
+        ctx.ws_handle = handle
         ctx.xp = x if packed else None
         ctx.names = names
         ctx.save_for_backward(hidden, *params)

@@ -32,6 +32,11 @@ class PreparedGraph:
     node_region_host: np.ndarray
     nnz_gcn: int
     nnz_cheb: int
+    # merged operator (one entry per distinct (row, col) with both weights) for the single-gather SpMM
+    m_rowptr: Optional[torch.Tensor] = None
+    m_col: Optional[torch.Tensor] = None
+    m_val_a: Optional[torch.Tensor] = None
+    m_val_l: Optional[torch.Tensor] = None
     _chunks: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = field(default_factory=dict)
 
     @property
@@ -181,6 +186,29 @@ def node_regions(region_index: Sequence[torch.Tensor], num_nodes: int) -> np.nda
     return filled.astype(np.int32)
 
 
+def merge_operators(rp_a, col_a, val_a, rp_l, col_l, val_l, num_nodes: int):
+    """Union of the two CSR patterns with both weights per entry (index bookkeeping on the device, once per graph).
+
+    Entries of one row are ordered by source id; an (i, j) pair present in both operators becomes one entry, a pair
+    present in one of them gets weight 0 in the other.  Duplicate edges of one operator are summed."""
+    dev = rp_a.device
+    n = num_nodes
+    nx = int(max(int(col_a.max()) if col_a.numel() else 0, int(col_l.max()) if col_l.numel() else 0)) + 1
+    rows_a = torch.repeat_interleave(torch.arange(n, device=dev), (rp_a[1:] - rp_a[:-1]).long())
+    rows_l = torch.repeat_interleave(torch.arange(n, device=dev), (rp_l[1:] - rp_l[:-1]).long())
+    keys = torch.cat([rows_a * nx + col_a.long(), rows_l * nx + col_l.long()])
+    uniq, inverse = torch.unique(keys, sorted=True, return_inverse=True)
+    na = col_a.numel()
+    va = torch.zeros(uniq.numel(), dtype=torch.float32, device=dev).index_add_(0, inverse[:na], val_a)
+    vl = torch.zeros(uniq.numel(), dtype=torch.float32, device=dev).index_add_(0, inverse[na:], val_l)
+    m_row = torch.div(uniq, nx, rounding_mode="floor")
+    m_col = (uniq - m_row * nx).to(torch.int32)
+    counts = torch.bincount(m_row, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return rowptr.contiguous(), m_col.contiguous(), va.contiguous(), vl.contiguous()
+
+
 def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], region_index: Sequence[torch.Tensor],
                   region_weight: Sequence[Optional[torch.Tensor]], num_nodes: int) -> PreparedGraph:
     """Build the stacked [A_hat; L~] operator.
@@ -201,6 +229,7 @@ def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], 
     val = torch.cat([val_a, val_l]).contiguous()
     if col.numel() == 0:
         raise ValueError("graph has no edges and no nodes")
+    m = merge_operators(rp_a, col_a, val_a, rp_l, col_l, val_l, num_nodes)
     return PreparedGraph(num_nodes=num_nodes, num_regions=len(region_index), rowptr=rowptr, col=col, val=val,
                          node_region=torch.from_numpy(owner).to(edge_index.device), node_region_host=owner,
-                         nnz_gcn=nnz_a, nnz_cheb=int(col_l.numel()))
+                         nnz_gcn=nnz_a, nnz_cheb=int(col_l.numel()), m_rowptr=m[0], m_col=m[1], m_val_a=m[2], m_val_l=m[3])

@@ -40,6 +40,17 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torc
     return out
 
 
+def spmm_dual(rowptr, col, val_a, val_l, x: torch.Tensor):
+    """(A x, L x) from the merged two-weight CSR in one gather pass; x.shape[1] % 32 == 0."""
+    x = _f32c(x, "x")
+    n = rowptr.numel() - 1
+    ya = torch.empty(n, x.shape[1], dtype=torch.float32, device=x.device)
+    yl = torch.empty_like(ya)
+    _lib.check(_lib.load().regt_spmm_dual(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val_a), _lib.ptr(val_l), _lib.ptr(x),
+                                          _lib.ptr(ya), _lib.ptr(yl), n, x.shape[1], _stream()), "regt_spmm_dual")
+    return ya, yl
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0, slope: float = 0.01):
     """act(a @ w.T + bias) on the fp32 matrix cores."""
     a, w = _f32c(a, "a"), _f32c(w, "w")

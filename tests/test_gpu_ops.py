@@ -105,6 +105,19 @@ def test_spmm_panel_variant_large_graph(R):
     assert torch.equal(got, again)
 
 
+def test_spmm_dual_matches_two_single_operator_passes(R):
+    n, width = 9000, 96
+    g = R.data.synthetic_regional_graph(n, 80000, 4, seed=2, p_intra=0.9)
+    pg = R.prepare_graph(g.edge_index.cuda(), None, [t.cuda() for t in g.region_index], [t.cuda() for t in g.region_attr], n)
+    x = torch.randn(n, width).cuda()
+    stacked = R.ops.spmm_csr(pg.rowptr, pg.col, pg.val, x)
+    ya, yl = R.ops.spmm_dual(pg.m_rowptr, pg.m_col, pg.m_val_a, pg.m_val_l, x)
+    assert float((ya - stacked[:n]).abs().max()) < 2e-6
+    assert float((yl - stacked[n:]).abs().max()) < 2e-6
+    # the merged pattern is the union: no more entries than the two operators together, at least as many as A_hat
+    assert pg.nnz_gcn <= pg.m_col.numel() <= pg.nnz_gcn + pg.nnz_cheb
+
+
 def test_spmm_empty_rows_and_hub(R):
     # node 0 receives every edge (hub), nodes 5.. receive none
     n = 300
