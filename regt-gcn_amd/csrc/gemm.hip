@@ -771,7 +771,7 @@ int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
 // One output element per group of 8 adjacent lanes: the K (and summed-batch) range is strided over the
 // group and combined with a fixed xor-shuffle tree (deterministic).  Sizes here are <= 64 x 256 x 256
 // outputs with K <= R*C, so the point is latency (enough waves), not FLOP/s.
-constexpr int SG_SPLIT = 8;
+template <int SG_SPLIT>   // 8: long K (weight compositions over K = C or R*C); 1: short K, many outputs
 __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
     const long per = (long)g.m * g.n;
     const int nb = g.sum_batch ? 1 : g.batch;
@@ -796,9 +796,11 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
                 for (int k = sub; k < g.k; k += SG_SPLIT) s = fmaf(A[(long)k * g.sak], B[(long)k * g.sbk], s);
             }
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
+        if (SG_SPLIT == 8) {
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+        }
         if (valid && sub == 0) {
             float* c = g.C + (long)b * g.scb + (long)i * g.sci + (long)j * g.scj;
             *c = g.accumulate ? *c + s : s;
@@ -808,10 +810,14 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(SmallGemm g) {
 
 int launch_small_gemm(const SmallGemm& g, hipStream_t st) {
     REGT_CHECK_ARG(g.m > 0 && g.n > 0 && g.batch > 0, "small_gemm: empty problem");
-    long total = (long)g.m * g.n * (g.sum_batch ? 1 : g.batch) * SG_SPLIT;
+    const long outputs = (long)g.m * g.n * (g.sum_batch ? 1 : g.batch);
+    const long klen = (long)g.k * (g.sum_batch ? g.batch : 1);
+    const bool split = klen >= 64;
+    long total = outputs * (split ? 8 : 1);
     int blocks = cdiv(total, 256);
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(small_gemm_kernel, dim3(blocks), dim3(256), 0, st, g);
+    if (blocks > 32768) blocks = 32768;
+    if (split) hipLaunchKernelGGL(small_gemm_kernel<8>, dim3(blocks), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(small_gemm_kernel<1>, dim3(blocks), dim3(256), 0, st, g);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

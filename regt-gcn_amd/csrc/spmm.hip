@@ -12,6 +12,8 @@
 // are in flight per lane before the first FMA.
 //
 // HBM-bound: algorithmic bytes = read X once + (col,val) + write Y.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace regt {
@@ -159,10 +161,12 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
 // The regional Laplacian rows are (almost) a subset of the full-graph rows: the same neighbour row
 // x[col] feeds both A_hat x and L~ x.  With a merged CSR that carries two weights per entry, one gather
 // serves both outputs -- half the gather volume of the stacked operator.  Same XCD/panel schedule as above.
+template <int PL>   // lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two)
 __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                               const float* __restrict__ val_a, const float* __restrict__ val_l,
                                                               const float* __restrict__ X, float* __restrict__ YA,
                                                               float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb) {
+    constexpr int ROWS = 256 / PL;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
     const int panel = li / nrb;
     if (panel >= npanels) return;
@@ -170,10 +174,10 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
     const int q = nnodes / 8, r8 = nnodes % 8;
     const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     const int csz = q + (xcd < r8 ? 1 : 0);
-    const int g = threadIdx.x >> 3, gl = threadIdx.x & 7;
-    if (rb * 32 + g >= csz) return;
-    const long row = c0 + rb * 32 + g;
-    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * 8 + gl;
+    const int g = threadIdx.x / PL, gl = threadIdx.x % PL;
+    if (rb * ROWS + g >= csz) return;
+    const long row = c0 + rb * ROWS + g;
+    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * PL + gl;
     float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), al = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
     for (int base = beg; base < end; base += 8) {
@@ -181,41 +185,48 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
         int myc = 0;
         float mya = 0.f, myl = 0.f;
         if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+        // all 8 gathers of the chunk in flight before the first FMA; entries >= n carry (col 0, weights 0)
+        float4 x[8];
+        float va[8], vl[8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h * 4 < n) {
-                float4 x[4];
-                float va[4], vl[4];
+        for (int e = 0; e < 8; ++e) {
+            const int c = __shfl(myc, e, PL);
+            va[e] = __shfl(mya, e, PL);
+            vl[e] = __shfl(myl, e, PL);
+            x[e] = e < n ? X4[(long)c * W4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = __shfl(myc, h * 4 + e, 8);
-                    va[e] = __shfl(mya, h * 4 + e, 8);
-                    vl[e] = __shfl(myl, h * 4 + e, 8);
-                    x[e] = X4[(long)c * W4];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    aa.x = fmaf(va[e], x[e].x, aa.x); aa.y = fmaf(va[e], x[e].y, aa.y);
-                    aa.z = fmaf(va[e], x[e].z, aa.z); aa.w = fmaf(va[e], x[e].w, aa.w);
-                    al.x = fmaf(vl[e], x[e].x, al.x); al.y = fmaf(vl[e], x[e].y, al.y);
-                    al.z = fmaf(vl[e], x[e].z, al.z); al.w = fmaf(vl[e], x[e].w, al.w);
-                }
-            }
+        for (int e = 0; e < 8; ++e) {
+            aa.x = fmaf(va[e], x[e].x, aa.x); aa.y = fmaf(va[e], x[e].y, aa.y);
+            aa.z = fmaf(va[e], x[e].z, aa.z); aa.w = fmaf(va[e], x[e].w, aa.w);
+            al.x = fmaf(vl[e], x[e].x, al.x); al.y = fmaf(vl[e], x[e].y, al.y);
+            al.z = fmaf(vl[e], x[e].z, al.z); al.w = fmaf(vl[e], x[e].w, al.w);
         }
     }
-    reinterpret_cast<float4*>(YA)[row * W4 + panel * 8 + gl] = aa;
-    reinterpret_cast<float4*>(YL)[row * W4 + panel * 8 + gl] = al;
+    reinterpret_cast<float4*>(YA)[row * W4 + panel * PL + gl] = aa;
+    reinterpret_cast<float4*>(YL)[row * W4 + panel * PL + gl] = al;
 }
 
 int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
                      float* YL, int nnodes, int W, hipStream_t st) {
     REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 32 == 0, "spmm_dual: width %d must be a multiple of 32 floats", W);
-    const int W4 = W / 4, npanels = W4 / 8;
-    const int nrb = cdiv(cdiv(nnodes, 8), 32);
+    const int W4 = W / 4;
+    static int pl_env = -1;
+    if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
+    // two cache lines per neighbour (halves the CSR re-reads) while the XCD's slice of X (chunk x 256 B) stays
+    // around the 4 MiB L2: measured 182 vs 197 us at cfg-3 (3.2 MB slice)
+    const bool wide = pl_env ? pl_env == 16 : (W4 % 16 == 0 && (long)cdiv(nnodes, 8) * 256 <= (7L << 19));
+    const int PL = wide ? 16 : 8;
+    const int npanels = W4 / PL;
+    const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
     const long grid = 8L * npanels * nrb;
     REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual: grid too large");
-    hipLaunchKernelGGL(spmm_dual_panel_kernel, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL, nnodes,
-                       W4, npanels, nrb);
+    if (wide)
+        hipLaunchKernelGGL(spmm_dual_panel_kernel<16>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL,
+                           nnodes, W4, npanels, nrb);
+    else
+        hipLaunchKernelGGL(spmm_dual_panel_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL,
+                           nnodes, W4, npanels, nrb);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

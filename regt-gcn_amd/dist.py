@@ -92,7 +92,12 @@ def exchange_boundary_rows(xp_ext: torch.Tensor, topo: ShardTopology, send_idx: 
         return xp_ext
     send = xp_ext.index_select(0, send_idx)                       # (max_boundary, W)
     recv = xp_ext[topo.n_local:]                                   # (world*max_boundary, W), contiguous view
-    if xp_ext.is_cuda:
+    if xp_ext.is_cuda and dist.get_backend(group) == "gloo":
+        # functional rehearsal of the multi-rank flow on a box without RCCL peers: stage through the host
+        host = [torch.empty(send.shape, dtype=send.dtype) for _ in range(topo.world)]
+        dist.all_gather(host, send.cpu(), group=group)
+        recv.copy_(torch.cat(host, dim=0))
+    elif xp_ext.is_cuda:
         dist.all_gather_into_tensor(recv, send, group=group)
     else:
         parts = list(recv.view(topo.world, topo.max_boundary, -1).unbind(0))
@@ -106,7 +111,12 @@ def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
     if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in grads:
         n = g.numel()
