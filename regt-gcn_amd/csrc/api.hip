@@ -76,7 +76,7 @@ struct Layout {
     // backward temporaries
     float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
-    int kchunk, nchunks, kchunk_head, nchunks_head, cb_npb, cb_blocks;
+    int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
     size_t bytes;
 };
 
@@ -111,10 +111,14 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, char* base) {
     L.dhp = take(M * C);
     L.dzr = take(M * 2 * C);
     L.dh = take(M * C);
-    long kc = ((M + 255) / 256 + 31) / 32 * 32;
+    long kc = ((M + 127) / 128 + 31) / 32 * 32;     // ~128 row chunks: 512-1024 wgrad workgroups, half the slab traffic of 256
     if (kc < 512) kc = 512;
     L.kchunk = (int)kc;
     L.nchunks = (int)((M + kc - 1) / kc);
+    long ks = ((M + 511) / 512 + 31) / 32 * 32;     // skinny (C x F) gradients: memory-bound, want >= 1024 small workgroups
+    if (ks < 512) ks = 512;
+    L.kchunk_s = (int)ks;
+    L.nchunks_s = (int)((M + ks - 1) / ks);
     long kh = ((N + 63) / 64 + 31) / 32 * 32;
     if (kh < 512) kh = 512;
     L.kchunk_head = (int)kh;
@@ -124,6 +128,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, char* base) {
     L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
     L.dp_partial = take((long)L.cb_blocks * T);
     long slab = (long)L.nchunks * (2 * C * C + 2 * C);
+    if ((long)L.nchunks_s * (2 * C * F + 2 * C) > slab) slab = (long)L.nchunks_s * (2 * C * F + 2 * C);
     long s2 = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
     long s3 = (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O);
     if (s2 > slab) slab = s2;
@@ -336,7 +341,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     }
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
     TRY(wgrad_full("wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
-    TRY(wgrad_full("wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGh, F, nullptr, st));
+    TRY(wgrad_full("wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, L.dGh, F, nullptr, st));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, L.h, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
         {
@@ -353,11 +358,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(launch_wgrad_reduce(r, st));
         }
     }
-    TRY(wgrad_full("wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, L.dGzr, F, nullptr, st));
+    TRY(wgrad_full("wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, L.dGzr, F, nullptr, st));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
-    TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dA0, F, dbpr, st));
+    TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dA0, F, dbpr, st));
     if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, L.slab, 0};
@@ -372,7 +377,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         r.group_stride = (long)C * F;
         TRY(launch_wgrad_reduce(r, st));
     } else {
-        TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk, L.nchunks, L.slab, dAall, F, nullptr, st));
+        TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dAall, F, nullptr, st));
     }
     // ---- back through the weight compositions (tiny) --------------------------------------------------
     PROF("compose_bwd", st);
@@ -476,7 +481,7 @@ int32_t regt_linear(const float* A, int64_t lda, int64_t M, int32_t K, const flo
 }
 
 static void wgrad_chunks(int64_t M, int* kchunk, int* nchunks) {
-    long kc = ((M + 255) / 256 + 31) / 32 * 32;
+    long kc = ((M + 127) / 128 + 31) / 32 * 32;
     if (kc < 512) kc = 512;
     *kchunk = (int)kc;
     *nchunks = (int)((M + kc - 1) / kc);

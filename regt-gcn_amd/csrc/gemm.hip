@@ -734,40 +734,58 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     return REGT_OK;
 }
 
-__global__ void wgrad_reduce_kernel(WgradReduceArgs a) {
+// Eight adjacent lanes share one output element: the chunk range is strided over them and combined with
+// a fixed xor-shuffle tree, so the order of the additions is fixed (deterministic) and small outputs
+// (the C x F gradients) still fill the chip.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
     const long per = (long)a.Nout * a.Nin;
     const long total = per * a.ngroups;
     const long ncs = a.colsum_out ? a.ncolsum : 0;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total + ncs; idx += (long)gridDim.x * blockDim.x) {
-        if (idx < total) {
-            int g = (int)(idx / per);
-            long e = idx - (long)g * per;
-            float s = 0.f;
-            for (int c = 0; c < a.nchunks; ++c)
-                if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + e];
-            int i = (int)(e / a.Nin), j = (int)(e % a.Nin);
-            float* o = a.out + (long)g * a.group_stride + (long)i * a.ldo + j;
-            *o = a.accumulate ? *o + s : s;
-        } else {
-            int i = (int)(idx - total);
-            float s = 0.f;
-            for (int c = 0; c < a.nchunks; ++c) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + i];
-            a.colsum_out[i] = a.accumulate ? a.colsum_out[i] + s : s;
+    const int sub = threadIdx.x & 7;
+    const long stride = (long)gridDim.x * blockDim.x / 8;
+    long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+    long wfirst = idx - (threadIdx.x % 64) / 8;
+    for (; wfirst < total + ncs; wfirst += stride, idx += stride) {
+        const bool valid = idx < total + ncs;
+        float s = 0.f;
+        int g = 0;
+        long e = 0;
+        if (valid) {
+            if (idx < total) {
+                g = (int)(idx / per);
+                e = idx - (long)g * per;
+                for (int c = sub; c < a.nchunks; c += 8)
+                    if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + e];
+            } else {
+                for (int c = sub; c < a.nchunks; c += 8) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + (idx - total)];
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        if (valid && sub == 0) {
+            if (idx < total) {
+                const int i = (int)(e / a.Nin), j = (int)(e % a.Nin);
+                float* o = a.out + (long)g * a.group_stride + (long)i * a.ldo + j;
+                *o = a.accumulate ? *o + s : s;
+            } else {
+                const int i = (int)(idx - total);
+                a.colsum_out[i] = a.accumulate ? a.colsum_out[i] + s : s;
+            }
         }
     }
 }
 
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(!(a.colsum_out && a.ngroups != 1), "wgrad_reduce: colsum only with one group");
-    long total = (long)a.Nout * a.Nin * a.ngroups + (a.colsum_out ? a.ncolsum : 0);
+    long total = ((long)a.Nout * a.Nin * a.ngroups + (a.colsum_out ? a.ncolsum : 0)) * 8;
     int blocks = cdiv(total, 256);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, a);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
 
-// ---- tiny strided batched GEMM --------------------------------------------------------------------
 // One output element per group of 8 adjacent lanes: the K (and summed-batch) range is strided over the
 // group and combined with a fixed xor-shuffle tree (deterministic).  Sizes here are <= 64 x 256 x 256
 // outputs with K <= R*C, so the point is latency (enough waves), not FLOP/s.
