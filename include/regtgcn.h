@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 1
+#define REGT_ABI_VERSION 2
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -125,6 +125,10 @@ typedef struct regt_graph {
     const int32_t* m_col;
     const float* m_val_a;
     const float* m_val_l;
+    /* overlap = 1: the regional graphs are NOT node-disjoint (the reference's "random" decomposition,
+     * load_dataset.py:324-329).  rowptr/col/val then hold (1+R)*N rows: A_hat, then one scaled Laplacian per
+     * region; node_region / chunk tables / merged operator are ignored. */
+    int32_t overlap;
 } regt_graph;
 
 typedef struct regt_params {
@@ -163,7 +167,7 @@ typedef struct regt_grads {
 
 /* Bytes of device workspace regt_forward / regt_backward need (same buffer for both: the forward
  * leaves the activations the backward reads). */
-size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks);
+size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks, int32_t overlap);
 
 /* x (N,F,T) -> pred (N,O), hidden (N,C).  RegionalTemporalGCN.forward / TemporalGCN.forward. */
 int32_t regt_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,

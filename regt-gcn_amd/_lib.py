@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libregtgcn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -30,7 +30,7 @@ class Dims(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("rowptr", vp), ("col", vp), ("val", vp), ("node_region", vp), ("chunk_tab", vp),
                 ("chunk_region", vp), ("n_chunks", C.c_int32),
-                ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp)]
+                ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp), ("overlap", C.c_int32)]
 
 
 _PARAM_FIELDS = [("attention", vp), ("conv_lin_w", vp * 3), ("conv_bias", vp * 3), ("gate_w", vp * 3),
@@ -62,7 +62,7 @@ SIGNATURES = {
                                 C.c_float, vp, C.c_int64, vp]),
     "regt_wgrad_slab_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "regt_wgrad": (C.c_int32, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, vp, vp, vp]),
-    "regt_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int32]),
+    "regt_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int32, C.c_int32]),
     "regt_forward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_forward_packed": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, C.c_int32, vp, vp, vp,
                                         C.c_size_t, vp]),

@@ -80,7 +80,7 @@ struct Layout {
     size_t bytes;
 };
 
-Layout make_layout(const regt_dims& d, int n_chunks_tab, char* base) {
+Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base) {
     Layout L{};
     const long N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
     const long M = N * T;
@@ -91,7 +91,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, char* base) {
         return base ? reinterpret_cast<float*>(base + o) : nullptr;
     };
     L.Xp = take(M * F);
-    L.AX = take(2 * M * F);
+    L.AX = take((overlap ? 1 + R : 2) * M * F);      // A_hat x, then L~ x (merged) or one L~_r x per region
     L.LX = L.AX ? L.AX + M * F : nullptr;
     L.h = take(M * C);
     L.ZR = take(M * 2 * C);
@@ -208,7 +208,9 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     }
     {
         PROF("spmm", st);
-        if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
+        if (g.overlap)
+            TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, (1 + R) * N, xp_ext ? x_rows : N, T * F, 1 + R, st));
+        else if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
             TRY(launch_spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, T * F, st));
         else
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, 2, st));
@@ -221,9 +223,13 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         GemmSegs S{};
         S.nseg = 2;
         S.seg[0] = make_seg(Xp, F, A0, nullptr, F, INT_MAX, F, true);
-        S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true, R > 1 ? SEG_REGION : 0, (long)C * F);
+        S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true,
+                            g.overlap ? SEG_REPEAT : (R > 1 ? SEG_REGION : 0), (long)C * F);
+        S.seg[1].a_rep_stride = M * F;
+        S.seg[1].nrep = R;
         S.node_region = g.node_region;
         S.row_div = T;
+        S.num_regions = R;
         EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
         PROF("gemm_regional", st);
         TRY(launch_gemm_bias_act(S, M, C, e, st));
@@ -363,7 +369,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
     TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dA0, F, dbpr, st));
-    if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
+    if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
+        for (int r = 0; r < R; ++r)
+            TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab,
+                           dAall + (long)r * C * F, F, nullptr, st));
+    } else if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, L.slab, 0};
         {
@@ -501,22 +511,22 @@ int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, 
     return wgrad_full("wgrad", dOut, ldd, N, A, lda, K, 0, M, kc, nc, slab, dW, ldw, dbias, (hipStream_t)st);
 }
 
-size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks) {
+size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks, int32_t overlap) {
     if (check_dims(dims)) return 0;
-    return make_layout(*dims, n_chunks, nullptr).bytes;
+    return make_layout(*dims, n_chunks, overlap, nullptr).bytes;
 }
 
 static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
                               const float* xp_ext, int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes,
                               regt_stream_t st) {
     TRY(check_dims(dims));
-    REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && graph->node_region, "regt_forward: graph incomplete");
+    REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && (graph->node_region || graph->overlap), "regt_forward: graph incomplete");
     TRY(check_ptrs(params, *dims));
     REGT_CHECK_ARG((x || xp_ext) && pred && hidden && ws, "regt_forward: NULL pointer");
     REGT_CHECK_ARG(al16(x) && al16(xp_ext) && al16(hidden) && al16(ws),
                    "regt_forward: x, hidden and workspace must be 16-byte aligned");
     REGT_CHECK_ARG(!xp_ext || x_rows >= dims->N, "regt_forward_packed: x_rows=%d < N=%d", x_rows, dims->N);
-    Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
+    Layout L = make_layout(*dims, graph->n_chunks, graph->overlap, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     return forward_impl(*dims, *graph, *params, x, xp_ext, x_rows, pred, hidden, L, (hipStream_t)st);
 }
@@ -537,7 +547,7 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
                       const float* dpred, const float* dhidden, const float* hidden, const float* x_packed, void* ws,
                       size_t ws_bytes, regt_stream_t st) {
     TRY(check_dims(dims));
-    REGT_CHECK_ARG(graph && graph->rowptr && graph->node_region, "regt_backward: graph incomplete");
+    REGT_CHECK_ARG(graph && graph->rowptr && (graph->node_region || graph->overlap), "regt_backward: graph incomplete");
     TRY(check_ptrs(params, *dims));
     REGT_CHECK_ARG(grads && dpred && hidden && ws, "regt_backward: NULL pointer");
     {
@@ -547,7 +557,7 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
         if (dims->regional) ok = ok && g.region_w && g.region_b;
         REGT_CHECK_ARG(ok, "regt_backward: a required gradient pointer is NULL (only `attention` may be NULL)");
     }
-    Layout L = make_layout(*dims, graph->n_chunks, (char*)ws);
+    Layout L = make_layout(*dims, graph->n_chunks, graph->overlap, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, (hipStream_t)st);
 }

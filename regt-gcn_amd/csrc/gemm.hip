@@ -202,7 +202,10 @@ static int fast_class(const GemmSegs& S, int N, bool vec) {
         if (g.flags & SEG_RELU_A) relu = 1;
         if (b && g.nsplit < N && g.nsplit % GBN != 0) return -1;      // a column tile must not straddle B0 | B1
         if (g.lda >= (1L << 22) || g.ldb >= (1L << 22)) return -1;    // 32-bit byte offsets inside a tile
-        iters += (long)cdiv(g.K, GBK) * ((g.flags & SEG_REGION) ? 8 : 1);   // region repeats are bounded per tile below
+        if ((g.flags & SEG_REPEAT) && g.a_rep_stride % 4 != 0) return -1;
+        // worst case: a row tile touches every region (node ids not sorted by region)
+        iters += (long)cdiv(g.K, GBK) * ((g.flags & SEG_REGION) ? (S.num_regions > 0 ? S.num_regions : 1)
+                                                                 : ((g.flags & SEG_REPEAT) ? g.nrep : 1));
     }
     if (relu && S.nseg != 1) return -1;
     if (iters > G_MAX_ITERS) return -1;

@@ -31,6 +31,8 @@ enum : int {
     SEG_REGION = 4,   // region-masked segment (see header comment)
     SEG_VEC_A = 8,    // A rows may be read as aligned float4
     SEG_VEC_B = 16,   // B rows may be read as aligned float4
+    SEG_REPEAT = 32,  // unmasked repeat: rep r = 0..nrep-1 uses A + r*a_rep_stride and B + r*b_region_stride
+                      // (overlapping regional graphs: one (L~_r x) operand and one composed weight per region)
 };
 
 struct GemmSeg {
@@ -43,6 +45,8 @@ struct GemmSeg {
     int K;
     int flags;
     long b_region_stride;
+    long a_rep_stride;
+    int nrep;
 };
 
 struct GemmSegs {
@@ -50,6 +54,7 @@ struct GemmSegs {
     GemmSeg seg[3];
     const int* node_region;  // (num nodes) or nullptr
     int row_div;             // global row -> node: grow / row_div
+    int num_regions;         // upper bound of the region ids in node_region (sizing of the fast-path table)
 };
 
 // Row map: local tile row r -> global row.
@@ -120,7 +125,7 @@ struct GemmCore {
         GemmSeg g;
 #define REGT_PICK(f) g.f = s == 0 ? S.seg[0].f : (s == 1 ? S.seg[1].f : S.seg[2].f)
         REGT_PICK(A); REGT_PICK(lda); REGT_PICK(B0); REGT_PICK(B1); REGT_PICK(ldb); REGT_PICK(nsplit);
-        REGT_PICK(K); REGT_PICK(flags); REGT_PICK(b_region_stride);
+        REGT_PICK(K); REGT_PICK(flags); REGT_PICK(b_region_stride); REGT_PICK(a_rep_stride); REGT_PICK(nrep);
 #undef REGT_PICK
         return g;
     }
@@ -128,8 +133,9 @@ struct GemmCore {
     __device__ __forceinline__ int seg_iters(int s) const {
         const int K = s == 0 ? S.seg[0].K : (s == 1 ? S.seg[1].K : S.seg[2].K);
         const int fl = s == 0 ? S.seg[0].flags : (s == 1 ? S.seg[1].flags : S.seg[2].flags);
+        const int nr = s == 0 ? S.seg[0].nrep : (s == 1 ? S.seg[1].nrep : S.seg[2].nrep);
         int nk = (K + GBK - 1) / GBK;
-        int reps = (fl & SEG_REGION) ? (rmax - rmin + 1) : 1;
+        int reps = (fl & SEG_REGION) ? (rmax - rmin + 1) : ((fl & SEG_REPEAT) ? nr : 1);
         return nk * reps;
     }
 
@@ -143,8 +149,9 @@ struct GemmCore {
         }
         const int K = s == 0 ? S.seg[0].K : (s == 1 ? S.seg[1].K : S.seg[2].K);
         int nk = (K + GBK - 1) / GBK;
+        const int fl = s == 0 ? S.seg[0].flags : (s == 1 ? S.seg[1].flags : S.seg[2].flags);
         t.seg = s;
-        t.region = rmin + it / nk;
+        t.region = ((fl & SEG_REGION) ? rmin : 0) + it / nk;
         t.k0 = (it % nk) * GBK;
         return t;
     }
@@ -153,6 +160,8 @@ struct GemmCore {
         TileIter ti = decode(it);
         const GemmSeg g = pick(ti.seg);
         const bool region = (g.flags & SEG_REGION) != 0;
+        const bool repeat = (g.flags & SEG_REPEAT) != 0;
+        const float* Abase = g.A + (repeat ? (long)ti.region * g.a_rep_stride : 0);
         const bool vecA = (g.flags & SEG_VEC_A) != 0, vecB = (g.flags & SEG_VEC_B) != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -163,14 +172,14 @@ struct GemmCore {
                 long gr = rm.grow(r);
                 bool ok = true;
                 if (region) ok = S.node_region[gr / S.row_div] == ti.region;
-                if (ok) v = ld4_guard(g.A + gr * g.lda + k, g.K - k, vecA);
+                if (ok) v = ld4_guard(Abase + gr * g.lda + k, g.K - k, vecA);
             }
             if (g.flags & SEG_RELU_A) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             ra[i] = v;
         }
-        const long boff = region ? (long)ti.region * g.b_region_stride : 0;
+        const long boff = (region || repeat) ? (long)ti.region * g.b_region_stride : 0;
         if (g.flags & SEG_BT) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

@@ -88,12 +88,14 @@ struct FastCore {
             for (int s = 0; s < S.nseg; ++s) {
                 const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
                 const bool reg = REGION && (g.flags & SEG_REGION);
-                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : 0;
+                const bool rep = (g.flags & SEG_REPEAT) != 0;
+                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : (rep ? g.nrep - 1 : 0);
                 for (int r = r0; r <= r1; ++r)
                     for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
                         ItDesc d;
-                        const long off = reg ? (long)r * g.b_region_stride : 0;
-                        d.A = g.A; d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
+                        const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
+                        d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
+                        d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
                         d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
                         table[n++] = d;
                     }

@@ -98,6 +98,7 @@ def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
     if graph.m_rowptr is not None:
         g.m_rowptr, g.m_col = graph.m_rowptr.data_ptr(), graph.m_col.data_ptr()
         g.m_val_a, g.m_val_l = graph.m_val_a.data_ptr(), graph.m_val_l.data_ptr()
+    g.overlap = 1 if graph.overlap else 0
     return g
 
 
@@ -148,7 +149,7 @@ class RegTGCNFunction(torch.autograd.Function):
                 raise ValueError(f"parameter {k} has shape {tuple(tens[k].shape)}, expected {shp}")
         dims = _lib.Dims(N, T, F, Cdim, R, O, H1, 1 if regional else 0, float(slope))
         gs = _graph_struct(graph, T)
-        wsb = lib.regt_workspace_bytes(C.byref(dims), gs.n_chunks)
+        wsb = lib.regt_workspace_bytes(C.byref(dims), gs.n_chunks, gs.overlap)
         if wsb == 0:
             _lib.check(1, "regt_workspace_bytes")
         handle = _WsHandle(_POOL.acquire(wsb, x.device))

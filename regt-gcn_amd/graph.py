@@ -37,6 +37,7 @@ class PreparedGraph:
     m_col: Optional[torch.Tensor] = None
     m_val_a: Optional[torch.Tensor] = None
     m_val_l: Optional[torch.Tensor] = None
+    overlap: bool = False       # True: (1+R)*N stacked rows, one Laplacian per region (regions share nodes)
     _chunks: Dict[int, Tuple[torch.Tensor, torch.Tensor, int]] = field(default_factory=dict)
 
     @property
@@ -164,18 +165,21 @@ def fingerprint(tensors: Sequence[Optional[torch.Tensor]]) -> int:
     return total
 
 
+class OverlappingRegions(ValueError):
+    """A node receives edges in more than one regional graph (e.g. the reference's 'random' decomposition)."""
+
+
 def node_regions(region_index: Sequence[torch.Tensor], num_nodes: int) -> np.ndarray:
-    """Region that owns each node's Laplacian row; raises if a node receives edges in two regional graphs."""
+    """Region that owns each node's Laplacian row; raises OverlappingRegions if a node receives edges in two
+    regional graphs."""
     owner = np.full(num_nodes, -1, dtype=np.int32)
     for r, ei in enumerate(region_index):
         e = ei.detach().cpu().numpy()
         dst = np.unique(e[1][e[0] != e[1]])
         clash = owner[dst] >= 0
         if clash.any():
-            raise NotImplementedError(
-                "regional graphs overlap: node %d receives edges in regions %d and %d. The fused path needs "
-                "node-disjoint regional graphs (the reference's 'regional' decomposition); overlapping "
-                "('random') decompositions are not implemented yet." % (int(dst[clash][0]), int(owner[dst[clash][0]]), r))
+            raise OverlappingRegions("node %d receives edges in regions %d and %d" %
+                                     (int(dst[clash][0]), int(owner[dst[clash][0]]), r))
         owner[dst] = r
     # nodes without regional in-edges have an all-zero Laplacian row: attach them to the previous
     # node's region so that region runs (and wgrad chunks) stay long.
@@ -220,7 +224,23 @@ def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], 
         raise ValueError("need one weight tensor (or None) per regional edge_index")
     rp_a, col_a, val_a = gcn_csr(edge_index, gcn_weight, num_nodes)
     w_all = [cheb_edge_weights(ei, ew, num_nodes) for ei, ew in zip(region_index, region_weight)]
-    owner = node_regions(region_index, num_nodes)
+    try:
+        owner = node_regions(region_index, num_nodes)
+    except OverlappingRegions:
+        # general mode: one Laplacian per region, (1+R)*N stacked rows; the pipeline then sums
+        # (L~_r x) A_r^T over all regions instead of selecting one region per node
+        rps, cols, vals, off = [rp_a], [col_a], [val_a], int(col_a.numel())
+        for ei, w in zip(region_index, w_all):
+            rp_r, col_r, val_r = raw_csr(ei, w, num_nodes)
+            rps.append(rp_r[1:] + off)
+            cols.append(col_r)
+            vals.append(val_r)
+            off += int(col_r.numel())
+        zeros = np.zeros(num_nodes, dtype=np.int32)
+        return PreparedGraph(num_nodes=num_nodes, num_regions=len(region_index), rowptr=torch.cat(rps).contiguous(),
+                             col=torch.cat(cols).contiguous(), val=torch.cat(vals).contiguous(),
+                             node_region=torch.from_numpy(zeros).to(edge_index.device), node_region_host=zeros,
+                             nnz_gcn=int(col_a.numel()), nnz_cheb=off - int(col_a.numel()), overlap=True)
     ei_all = torch.cat([ei for ei in region_index], dim=1)
     rp_l, col_l, val_l = raw_csr(ei_all, torch.cat(w_all), num_nodes)
     nnz_a = int(col_a.numel())

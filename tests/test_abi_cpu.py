@@ -22,7 +22,7 @@ def _declared():
 def test_every_declared_symbol_is_exported_and_bound():
     lib = R.load_library()
     names = _declared()
-    assert len(names) >= 19
+    assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/regtgcn.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes prototype in _lib.SIGNATURES"
@@ -33,10 +33,11 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_host_side_validation_without_gpu():
     lib = R.load_library()
     d = _lib.Dims(10, 6, 7, 256, 5, 1, 128, 1, 0.01)            # F = 7 is not a multiple of 4
-    assert lib.regt_workspace_bytes(ctypes.byref(d), 1) == 0
+    assert lib.regt_workspace_bytes(ctypes.byref(d), 1, 0) == 0
     assert b"multiple of 4" in lib.regt_last_error()
     d = _lib.Dims(104, 6, 8, 256, 5, 1, 128, 1, 0.01)
-    assert lib.regt_workspace_bytes(ctypes.byref(d), 1) > 104 * 6 * 256 * 4 * 9
+    assert lib.regt_workspace_bytes(ctypes.byref(d), 1, 0) > 104 * 6 * 256 * 4 * 9
+    assert lib.regt_workspace_bytes(ctypes.byref(d), 1, 1) > lib.regt_workspace_bytes(ctypes.byref(d), 1, 0)
     rc = lib.regt_spmm_csr(None, None, None, None, None, 1, 1, 4, None)
     assert rc != 0 and b"NULL" in lib.regt_last_error()
     assert lib.regt_graph_workspace_bytes(1000, 100) > 0

@@ -100,5 +100,5 @@ def test_node_regions_fill_and_overlap():
     b = torch.tensor([[4, 5], [5, 4]])
     own = R.graph.node_regions([a, b], 7)
     assert own.tolist() == [0, 0, 0, 0, 1, 1, 1]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(R.graph.OverlappingRegions):
         R.graph.node_regions([a, torch.tensor([[3], [1]])], 7)

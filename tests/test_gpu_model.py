@@ -132,6 +132,38 @@ def test_regt_matches_oracle_on_synthetic_regional_graph(R, n, e, regions, f, t,
         np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=TOL, rtol=1e-4, err_msg=k)
 
 
+@pytest.mark.parametrize("n,e,regions,f,t,o", [(900, 6000, 5, 8, 6, 1), (3000, 30000, 3, 32, 12, 2)])
+def test_overlapping_random_decomposition_matches_oracle(R, n, e, regions, f, t, o):
+    """The reference's 'random' decomposition (load_dataset.py:324-329): the edges of the full graph are dealt
+    to R regional graphs at random, so every node has edges in several of them (general, non-disjoint mode)."""
+    g = torch.Generator().manual_seed(n)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    keep = src != dst
+    ei = torch.stack([src[keep], dst[keep]])
+    w = torch.rand(ei.shape[1], generator=g) * 2925 + 75
+    part = torch.randint(0, regions, (ei.shape[1],), generator=g)
+    ri = [ei[:, part == r].contiguous() for r in range(regions)]
+    rw = [w[part == r].contiguous() for r in range(regions)]
+    x = torch.rand(n, f, t, generator=g)
+    y = torch.rand(n, o, generator=g)
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=4)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    pred_o, hid_o = M.regional_temporal_gcn(po, x, ei, ri, rw)
+    torch.mean((pred_o - y) ** 2).backward()
+    mod = R.RegionalTemporalGCN(f, n, t, o, num_regions=regions)
+    mod.load_state_dict(p)
+    mod = mod.cuda()
+    pred, hidden = mod(x.cuda(), ei.cuda(), _cuda_list(ri), _cuda_list(rw))
+    torch.mean((pred - y.cuda()) ** 2).backward()
+    assert float((pred.detach().cpu() - pred_o.detach()).abs().max()) < TOL
+    assert float((hidden.detach().cpu() - hid_o.detach()).abs().max()) < TOL
+    for k, q in mod.named_parameters():
+        if k in M.UNUSED_PARAMS:
+            continue
+        np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=TOL, rtol=1e-4, err_msg=k)
+
+
 def test_forward_is_deterministic_and_graph_is_cached(R, tpims):
     n = tpims["node_data"].shape[0]
     p = M.init_params("RegionalTemporalGCN", 8, 6, 1, num_nodes=n, seed=11)

@@ -190,8 +190,8 @@ def test_prepared_graph_tpims(R, tpims):
         assert np.all(g.node_region_host[bounds[r]:bounds[r + 1]] == r)
 
 
-def test_overlapping_regions_rejected(R):
+def test_overlapping_regions_take_the_general_layout(R):
     a = torch.tensor([[0, 1], [1, 0]]).cuda()
     b = torch.tensor([[2, 1], [1, 2]]).cuda()      # node 1 also receives an edge in region b
-    with pytest.raises(NotImplementedError):
-        R.prepare_graph(a, None, [a, b], [None, None], 3)
+    g = R.prepare_graph(a, None, [a, b], [None, None], 3)
+    assert g.overlap and g.rowptr.numel() == 3 * 3 + 1 and g.m_rowptr is None
