@@ -192,6 +192,10 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
  * roofline figures).  collect() waits for the recorded events and writes "name count total_ms"
  * lines into buf. */
 int32_t regt_profile_enable(int32_t on);
+/* Optional (environment REGT_HIPGRAPH=1; =2 for every size): small problems (N*T <= 32768 rows) replay a captured
+ * hipGraph from the second call on identical buffers.  Off by default -- not faster at TPIMS size.  out[0..5] = forward {eager, captured, replayed},
+ * backward {eager, captured, replayed} call counts. */
+int32_t regt_graph_stats(int64_t* out);
 int32_t regt_profile_collect(char* buf, size_t buf_bytes);
 
 /* loss = mean((pred - y)^2) over `count` entries with mean taken over `global_count`

@@ -68,6 +68,7 @@ SIGNATURES = {
                                         C.c_size_t, vp]),
     "regt_backward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), C.POINTER(Grads), vp, vp, vp,
                                   vp, vp, C.c_size_t, vp]),
+    "regt_graph_stats": (C.c_int32, [C.POINTER(C.c_int64)]),
     "regt_profile_enable": (C.c_int32, [C.c_int32]),
     "regt_profile_collect": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "regt_mse_loss_grad": (C.c_int32, [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]),

@@ -109,6 +109,35 @@ int launch_att_bwd(const float* dp_partial, int nblocks, const float* probs, flo
     return REGT_OK;
 }
 
+// Tiny device-to-device copies / clears as kernels: inside a captured hipGraph a memcpy / memset node costs far
+// more than a kernel node, and these sit on the launch-bound path of small graphs.
+__global__ void copy_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void zero_f32_kernel(float4* __restrict__ dst, long n4, float* __restrict__ tail, int ntail) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0.f;
+}
+
+int launch_copy_f32(float* dst, const float* src, long n, hipStream_t st) {
+    int blocks = cdiv(n, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(copy_f32_kernel, dim3(blocks), dim3(256), 0, st, dst, src, n);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
+int launch_zero_f32(float* dst, long n, hipStream_t st) {
+    REGT_CHECK_ARG((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "zero_f32: destination must be 16-byte aligned");
+    const long n4 = n / 4;
+    int blocks = cdiv(n4 > 0 ? n4 : 1, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<float4*>(dst), n4, dst + 4 * n4, (int)(n - 4 * n4));
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 // loss = scale * sum (pred - y)^2 ;  dpred = 2 * scale * (pred - y)     (scale = 1 / (N_global * O))
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* y, float* dpred, float* loss_out,
                                                        long n, float scale) {

@@ -415,7 +415,7 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         const long M = (long)a.num_nodes * a.T;
         const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
         REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
-        REGT_CHECK_HIP(hipMemsetAsync(a.OH, 0, (size_t)a.num_nodes * a.C * sizeof(float), st));
+        if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
         hipLaunchKernelGGL(gemm_cand_flat_kernel, dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
         static bool attr_done2 = false;

@@ -114,6 +114,8 @@ struct CellBwdArgs {
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st);
 int cell_bwd_blocks(int num_nodes, int nodes_per_block);
 int launch_att_bwd(const float* dp_partial, int nblocks, const float* probs, float* datt, int T, hipStream_t st);
+int launch_copy_f32(float* dst, const float* src, long n, hipStream_t st);
+int launch_zero_f32(float* dst, long n, hipStream_t st);
 int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st);
 
 }  // namespace regt

@@ -28,3 +28,25 @@ for i in range(K): step(i)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"TPIMS N={n} T={T}: {1e3*dt/K:.3f} ms/step  {K/dt:.1f} snapshots/s")
+
+import ctypes
+from regtgcn_amd import _lib
+st = (ctypes.c_int64 * 6)()
+_lib.load().regt_graph_stats(st)
+print("graph stats fwd eager/captured/replayed:", st[0], st[1], st[2], " bwd:", st[3], st[4], st[5])
+
+# per-stage device time (HIP events inside the library; graphs are bypassed while profiling)
+lib = _lib.load()
+lib.regt_profile_enable(1)
+for i in range(50): step(i)
+torch.cuda.synchronize()
+lib.regt_profile_enable(0)
+buf = (ctypes.c_char * 16384)()
+lib.regt_profile_collect(buf, 16384)
+rows = [l.split() for l in buf.value.decode().splitlines()]
+tot = 0.0
+for name, cnt, ms in sorted(rows, key=lambda r: -float(r[2])):
+    per = float(ms) / 50 * 1e3
+    tot += per
+    print(f"  {name:18s} {int(cnt)//50:3d} launches/step  {per:8.1f} us/step")
+print(f"  sum {tot:.1f} us/step")
