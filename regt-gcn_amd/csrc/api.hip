@@ -12,6 +12,7 @@
 #include <stdarg.h>
 
 #include <functional>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -245,26 +246,37 @@ SmallGemm sg(const float* A, long sai, long sak, long sab, const float* B, long 
     return SmallGemm{A, sai, sak, sab, B, sbk, sbj, sbb, C, sci, scj, scb, m, n, k, batch, sum_batch, accumulate};
 }
 
+SgTerm term(const float* A, long sai, long sak, long sab, const float* B, long sbk, long sbj, long sbb, int k, int batch = 1,
+            int sum_batch = 0) {
+    return SgTerm{A, sai, sak, sab, B, sbk, sbj, sbb, k, batch, sum_batch};
+}
+void add_task(SgBatch& b, float* C, long sci, long scj, long scb, int m, int n, int nbatch, const float* init, long init_si,
+              std::initializer_list<SgTerm> terms) {
+    SgTask& t = b.task[b.ntask++];
+    t = SgTask{};
+    t.C = C; t.sci = sci; t.scj = scj; t.scb = scb; t.m = m; t.n = n; t.nbatch = nbatch; t.init = init; t.init_si = init_si;
+    for (const SgTerm& q : terms) t.term[t.nterm++] = q;
+}
+
+// All weight compositions of one step in ONE launch (SURVEY/DESIGN section 3, item 2).
 int compose_forward(const regt_dims& d, const regt_params& p, const Layout& L, hipStream_t st) {
     const int C = d.C, F = d.F, R = d.R;
+    const long RC = (long)R * C;
+    SgBatch b{};
     if (d.regional) {
-        // A0 = sum_r Wl_r W0            (C,F)
-        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_w0, F, 1, 0, L.A0, F, 1, 0, C, F, C, R, 1, 0), st));
-        // A_r = Wl_r W1                 (R,C,F)
-        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_w1, F, 1, 0, L.Aall, F, 1, (long)C * F, C, F, C, R, 0, 0), st));
-        // b' = sum_r Wl_r b_c + b_l
-        TRY(launch_copy_f32(L.bprime, p.region_b, C, st));
-        TRY(launch_small_gemm(sg(p.region_w, (long)R * C, 1, C, p.cheb_bias, 1, 0, 0, L.bprime, 1, 0, 0, C, 1, C, R, 1, 1), st));
+        // A0 = sum_r Wl_r W0 ;  A_r = Wl_r W1 ;  b' = sum_r Wl_r b_c + b_l
+        add_task(b, L.A0, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, RC, 1, C, p.cheb_w0, F, 1, 0, C, R, 1)});
+        add_task(b, L.Aall, F, 1, (long)C * F, C, F, R, nullptr, 0, {term(p.region_w, RC, 1, C, p.cheb_w1, F, 1, 0, C)});
+        add_task(b, L.bprime, 1, 0, 0, C, 1, 1, p.region_b, 1, {term(p.region_w, RC, 1, C, p.cheb_bias, 1, 0, 0, C, R, 1)});
     }
     for (int k = 0; k < 3; ++k) {
         float* G = k < 2 ? L.Gzr + (long)k * C * F : L.Gh;
         float* c = k < 2 ? L.czr + (long)k * C : L.ch;
         // G_k = U_k[:, :C] V_k ;  c_k = U_k[:, :C] beta_k + u_k
-        TRY(launch_small_gemm(sg(p.gate_w[k], 2L * C, 1, 0, p.conv_lin_w[k], F, 1, 0, G, F, 1, 0, C, F, C, 1, 0, 0), st));
-        TRY(launch_copy_f32(c, p.gate_b[k], C, st));
-        TRY(launch_small_gemm(sg(p.gate_w[k], 2L * C, 1, 0, p.conv_bias[k], 1, 0, 0, c, 1, 0, 0, C, 1, C, 1, 0, 1), st));
+        add_task(b, G, F, 1, 0, C, F, 1, nullptr, 0, {term(p.gate_w[k], 2L * C, 1, 0, p.conv_lin_w[k], F, 1, 0, C)});
+        add_task(b, c, 1, 0, 0, C, 1, 1, p.gate_b[k], 1, {term(p.gate_w[k], 2L * C, 1, 0, p.conv_bias[k], 1, 0, 0, C)});
     }
-    return REGT_OK;
+    return launch_small_gemm_multi(b, st);
 }
 
 int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, const float* xp_ext,
@@ -465,30 +477,39 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     } else {
         TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dAall, F, nullptr, st));
     }
-    // ---- back through the weight compositions (tiny) --------------------------------------------------
+    // ---- back through the weight compositions (tiny; two launches) ---------------------------------------
     PROF("compose_bwd", st);
-    for (int k = 0; k < 3; ++k) {
-        const float* dG = k < 2 ? L.dGzr + (long)k * C * F : L.dGh;
-        const float* dc = k < 2 ? L.dczr + (long)k * C : L.dch;
-        // dU_k[:, :C] = dG_k V_k^T + dc_k beta_k^T
-        TRY(launch_small_gemm(sg(dG, F, 1, 0, p.conv_lin_w[k], 1, F, 0, gr.gate_w[k], 2L * C, 1, 0, C, C, F, 1, 0, 0), st));
-        TRY(launch_small_gemm(sg(dc, 1, 0, 0, p.conv_bias[k], 0, 1, 0, gr.gate_w[k], 2L * C, 1, 0, C, C, 1, 1, 0, 1), st));
-        // dV_k = U_k[:, :C]^T dG_k ; dbeta_k = U_k[:, :C]^T dc_k ; du_k = dc_k
-        TRY(launch_small_gemm(sg(p.gate_w[k], 1, 2L * C, 0, dG, F, 1, 0, gr.conv_lin_w[k], F, 1, 0, C, F, C, 1, 0, 0), st));
-        TRY(launch_small_gemm(sg(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, gr.conv_bias[k], 1, 0, 0, C, 1, C, 1, 0, 0), st));
-        TRY(launch_copy_f32(gr.gate_b[k], dc, C, st));
+    {
+        SgBatch b{};
+        for (int k = 0; k < 3; ++k) {
+            const float* dG = k < 2 ? L.dGzr + (long)k * C * F : L.dGh;
+            const float* dc = k < 2 ? L.dczr + (long)k * C : L.dch;
+            // dU_k[:, :C] = dG_k V_k^T + dc_k beta_k^T
+            add_task(b, gr.gate_w[k], 2L * C, 1, 0, C, C, 1, nullptr, 0,
+                     {term(dG, F, 1, 0, p.conv_lin_w[k], 1, F, 0, F), term(dc, 1, 0, 0, p.conv_bias[k], 0, 1, 0, 1)});
+            // dV_k = U_k[:, :C]^T dG_k ; dbeta_k = U_k[:, :C]^T dc_k
+            add_task(b, gr.conv_lin_w[k], F, 1, 0, C, F, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dG, F, 1, 0, C)});
+            add_task(b, gr.conv_bias[k], 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, C)});
+        }
+        TRY(launch_small_gemm_multi(b, st));
     }
-    if (d.regional) {
-        const long RC = (long)R * C;
-        // dWl_r = dA_r W1^T + dA0 W0^T + db' b_c^T
-        TRY(launch_small_gemm(sg(L.dAall, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, gr.region_w, RC, 1, C, C, C, F, R, 0, 0), st));
-        TRY(launch_small_gemm(sg(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, gr.region_w, RC, 1, C, C, C, F, R, 0, 1), st));
-        TRY(launch_small_gemm(sg(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, gr.region_w, RC, 1, C, C, C, 1, R, 0, 1), st));
-        // dW0 = (sum_r Wl_r)^T dA0 ; dW1 = sum_r Wl_r^T dA_r ; db_c = (sum_r Wl_r)^T db' ; db_l = db'
-        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dA0, F, 1, 0, gr.cheb_w0, F, 1, 0, C, F, C, R, 1, 0), st));
-        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dAall, F, 1, (long)C * F, gr.cheb_w1, F, 1, 0, C, F, C, R, 1, 0), st));
-        TRY(launch_small_gemm(sg(p.region_w, 1, RC, C, L.dbprime, 1, 0, 0, gr.cheb_bias, 1, 0, 0, C, 1, C, R, 1, 0), st));
-        TRY(launch_copy_f32(gr.region_b, L.dbprime, C, st));
+    {
+        SgBatch b{};
+        for (int k = 0; k < 3; ++k)      // du_k = dc_k
+            add_task(b, gr.gate_b[k], 1, 0, 0, C, 1, 1, k < 2 ? L.dczr + (long)k * C : L.dch, 1, {});
+        if (d.regional) {
+            const long RC = (long)R * C;
+            // dWl_r = dA_r W1^T + dA0 W0^T + db' b_c^T
+            add_task(b, gr.region_w, RC, 1, C, C, C, R, nullptr, 0,
+                     {term(L.dAall, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, F), term(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, F),
+                      term(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, 1)});
+            // dW0 = (sum_r Wl_r)^T dA0 ; dW1 = sum_r Wl_r^T dA_r ; db_c = (sum_r Wl_r)^T db' ; db_l = db'
+            add_task(b, gr.cheb_w0, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dA0, F, 1, 0, C, R, 1)});
+            add_task(b, gr.cheb_w1, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dAall, F, 1, (long)C * F, C, R, 1)});
+            add_task(b, gr.cheb_bias, 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dbprime, 1, 0, 0, C, R, 1)});
+            add_task(b, gr.region_b, 1, 0, 0, C, 1, 1, L.dbprime, 1, {});
+        }
+        TRY(launch_small_gemm_multi(b, st));
     }
     return REGT_OK;
 }

@@ -843,4 +843,54 @@ int launch_small_gemm(const SmallGemm& g, hipStream_t st) {
     return REGT_OK;
 }
 
+__global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
+    int ti = 0;
+    while (ti + 1 < B.ntask && (int)blockIdx.x >= B.block_start[ti + 1]) ++ti;
+    // field-wise copy of the selected task (scalar selects; no dynamically indexed kernarg struct in scratch)
+    const SgTask& T = B.task[ti];
+    const long per = (long)T.m * T.n, total = per * T.nbatch;
+    const int sub = threadIdx.x & 7;
+    const long idx = ((long)(blockIdx.x - B.block_start[ti]) * 256 + threadIdx.x) / 8;
+    const bool valid = idx < total;
+    float s = 0.f;
+    int b = 0, i = 0, j = 0;
+    if (valid) {
+        b = (int)(idx / per);
+        const long e = idx - (long)b * per;
+        i = (int)(e / T.n);
+        j = (int)(e % T.n);
+        for (int t = 0; t < T.nterm; ++t) {
+            const SgTerm& q = T.term[t];
+            const int b0 = q.sum_batch ? 0 : b, b1 = q.sum_batch ? q.batch : b + 1;
+            for (int bb = b0; bb < b1; ++bb) {
+                const float* A = q.A + (long)bb * q.sab + (long)i * q.sai;
+                const float* Bp = q.B + (long)bb * q.sbb + (long)j * q.sbj;
+                for (int k = sub; k < q.k; k += 8) s = fmaf(A[(long)k * q.sak], Bp[(long)k * q.sbk], s);
+            }
+        }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (valid && sub == 0) {
+        if (T.init) s += T.init[(long)i * T.init_si];
+        T.C[(long)b * T.scb + (long)i * T.sci + (long)j * T.scj] = s;
+    }
+}
+
+int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
+    REGT_CHECK_ARG(b.ntask > 0 && b.ntask <= SG_MAX_TASKS, "small_gemm_multi: %d tasks", b.ntask);
+    int blocks = 0;
+    for (int t = 0; t < b.ntask; ++t) {
+        b.block_start[t] = blocks;
+        const long outputs = (long)b.task[t].m * b.task[t].n * b.task[t].nbatch;
+        REGT_CHECK_ARG(outputs > 0, "small_gemm_multi: empty task %d", t);
+        blocks += cdiv(outputs * 8, 256);
+    }
+    b.block_start[b.ntask] = blocks;
+    hipLaunchKernelGGL(small_gemm_multi_kernel, dim3(blocks), dim3(256), 0, st, b);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 }  // namespace regt

@@ -87,6 +87,28 @@ struct SmallGemm {
 };
 int launch_small_gemm(const SmallGemm& g, hipStream_t st);
 
+// Several such products in ONE launch (the per-step weight compositions are ~27 tiny dependent-free GEMMs; one
+// launch each would dominate the step at TPIMS size).  out[b][i,j] = init[i] + sum_terms sum_k A[..]*B[..].
+struct SgTerm {
+    const float* A; long sai, sak, sab;
+    const float* B; long sbk, sbj, sbb;
+    int k, batch, sum_batch;     // sum_batch: reduce over `batch` operand pairs; else use the output's batch index
+};
+struct SgTask {
+    float* C; long sci, scj, scb;
+    int m, n, nbatch;            // output (nbatch, m, n)
+    const float* init; long init_si;   // optional init[i*init_si] added to every column (nullptr: 0)
+    int nterm;
+    SgTerm term[3];
+};
+constexpr int SG_MAX_TASKS = 10;
+struct SgBatch {
+    int ntask;
+    int block_start[SG_MAX_TASKS + 1];
+    SgTask task[SG_MAX_TASKS];
+};
+int launch_small_gemm_multi(SgBatch& b, hipStream_t st);
+
 // ---- graph preparation (graph.hip) ---------------------------------------------------------------
 size_t graph_workspace_bytes(long E, int N);
 int graph_gcn_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,
