@@ -189,11 +189,11 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.dzr = take(M * 2 * C);
     L.dh = take(M * C);
     long kc = ((M + 127) / 128 + 31) / 32 * 32;     // ~128 row chunks: 512-1024 wgrad workgroups, half the slab traffic of 256
-    if (kc < 512) kc = 512;
+    if (kc < 128) kc = 128;                          // small graphs: short K loops in many workgroups (latency-bound regime)
     L.kchunk = (int)kc;
     L.nchunks = (int)((M + kc - 1) / kc);
     long ks = ((M + 511) / 512 + 31) / 32 * 32;     // skinny (C x F) gradients: memory-bound, want >= 1024 small workgroups
-    if (ks < 512) ks = 512;
+    if (ks < 128) ks = 128;
     L.kchunk_s = (int)ks;
     L.nchunks_s = (int)((M + ks - 1) / ks);
     long kh = ((N + 63) / 64 + 31) / 32 * 32;

@@ -56,7 +56,7 @@ def region_chunks(node_region: np.ndarray, periods: int):
     """Split the (node*T + t) row space into chunks that never straddle a region boundary."""
     n = len(node_region)
     m = n * periods
-    kc = max(512, ((m + 511) // 512 + 31) // 32 * 32)    # same granularity as the other skinny gradients
+    kc = max(128, ((m + 511) // 512 + 31) // 32 * 32)    # same granularity as the other skinny gradients
     change = np.flatnonzero(np.diff(node_region)) + 1
     starts = np.concatenate([[0], change]).astype(np.int64)
     ends = np.concatenate([change, [n]]).astype(np.int64)
