@@ -38,6 +38,15 @@ if ROOT not in sys.path:
 PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs, 2.4 GHz
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s is the measured achievable copy rate)
 
+# HBM bytes per launch of the dominant kernels at cfg-3 on one GPU, from rocprofv3 PMC passes of this same command
+# (profiles/r01_c_pmc_hbm_summary.txt): 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B/lane streaming reads --
+# MI355X_MICROARCH.md, HBM section; calibrated here on cell_bwd, whose 3.7 GB of float4 reads show as 2.08e6 KB) + WRITE_SIZE.
+PMC_TRAFFIC_CFG3 = {
+    "gemm_gates": 2 * 1.255e6 * 1024 + 3.600e6 * 1024,        # h (twice: A operand and R-half epilogue) + Âx; ZR + q written
+    "dgrad_gates": 2 * 2.558e6 * 1024 + 1.200e6 * 1024,
+    "wgrad_Uzr": 2 * 2.433e6 * 1024 + 3.564e4 * 1024,
+}
+
 WORKLOADS = {
     # name: (nodes, edges, regions, F, T, O) per GPU
     "cfg3": (100_000, 1_000_000, 8, 32, 12, 1),
@@ -223,8 +232,9 @@ def main():
             cnt = stages[dom][0]
             avg_s = tot_ms / cnt * 1e-3
             achieved = stage_flops(dom, M, C, F) / avg_s / 1e12
+            traffic = PMC_TRAFFIC_CFG3.get(dom) if (args.workload == "cfg3" and world == 1) else None
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS,
-                               "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                                "avg_ms": avg_s * 1e3, "flops_per_launch": stage_flops(dom, M, C, F)}
             if "spmm" in stages:
                 c, ms = stages["spmm"]
