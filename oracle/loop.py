@@ -56,3 +56,20 @@ def evaluate(params, forward: Callable, xs, ys) -> Tuple[float, float]:
     se = [((forward(params, x)[0] - y) ** 2) for x, y in zip(xs, ys)]
     m = torch.cat(se, dim=0).mean()
     return float(m.sqrt()), float(m)
+
+
+@torch.no_grad()
+def predict_metrics(params, forward: Callable, xs, ys) -> Tuple[float, float, float]:
+    """predict.py:141-194: (MAE, RMSE, MAPE %) -- absolute error, squared error and absolute error over the
+    95th percentile of the snapshot's targets (numpy percentile, snapshot skipped if the ratio has an inf)."""
+    import numpy as np
+    mae, mse, mape = [], [], []
+    for x, y in zip(xs, ys):
+        out = forward(params, x)[0]
+        mae.append(np.abs((y - out).cpu()))
+        mse.append(((y - out) ** 2).cpu())
+        ratio = np.abs((y - out).cpu() / np.percentile(y.cpu(), q=95))
+        if np.isinf(ratio).any() == 0:
+            mape.append(ratio)
+    return (float(torch.cat(mae, dim=0).mean()), float(torch.cat(mse, dim=0).mean().sqrt()),
+            float(torch.cat(mape, dim=0).mean()) * 100)

@@ -272,6 +272,24 @@ def test_training_loop_matches_reference_trajectory(R, tpims):
     np.testing.assert_allclose(np.array(metrics), g["metrics"], atol=1e-5)
 
 
+def test_predict_metrics_with_shipped_checkpoint(R, tpims):
+    """predict.py's MAE / RMSE / MAPE on the test split with the reference's trained checkpoint: HIP module vs oracle."""
+    from oracle import loop as oloop
+    n = tpims["node_data"].shape[0]
+    p = torch.load(os.path.join(GOLDEN, "ref_ckpt_in6_out1_epoch50.pt"), map_location="cpu", weights_only=True)
+    xs, ys = R.data.snapshot_windows(tpims["node_data"][:, :, :30], 6, 1)
+    (_, _), (vx, vy) = R.train.split(xs, ys, 0.2)
+    ri, rw = region_lists(tpims)
+    want = oloop.predict_metrics(p, lambda prm, x: M.regional_temporal_gcn(prm, x.contiguous(), tpims["edge_index"], ri, rw), vx, vy)
+    mod = R.RegionalTemporalGCN(8, n, 6, 1)
+    mod.load_state_dict(p)
+    mod = mod.cuda()
+    graph = mod.prepare_graph(tpims["edge_index"].cuda(), _cuda_list(ri), _cuda_list(rw))
+    got = R.evaluate.predict_metrics(mod, _cuda_list(vx), _cuda_list(vy), graph)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6)
+    assert 0.05 < got[1] < 0.2          # RMSE in the band of the paper's 0.086 (BASELINE.md)
+
+
 def test_cpu_tensors_are_refused(R):
     mod = R.RegionalTemporalGCN(8, 10, 6, 1)
     with pytest.raises(R.RegtError):
