@@ -444,7 +444,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const int lr = lane & 31, lh = lane >> 5;
     const int wr = BNW == 128 ? (wid >> 1) : wid, wc = BNW == 128 ? (wid & 1) : 0;
     const int tiles_i = (a.Nout + 127) / 128, tiles_j = (a.Nin + BNW - 1) / BNW;
-    const int tile = blockIdx.x % (tiles_i * tiles_j), chunk = blockIdx.x / (tiles_i * tiles_j);
+    // XCD-aware mapping: all tiles of one row chunk run on the same XCD (workgroup b lands on XCD b % 8), back to
+    // back, so the chunk's P and Q rows are fetched from HBM once and served to the other tiles from that XCD's L2.
+    const int tpc = tiles_i * tiles_j;
+    int tile, chunk;
+    {
+        const int nfull = (a.nchunks / 8) * 8;                 // chunks that can be dealt 8 at a time
+        const int b = blockIdx.x;
+        if (b < nfull * tpc) {
+            const int xcd = b & 7, li = b >> 3;
+            chunk = (li / tpc) * 8 + xcd;
+            tile = li % tpc;
+        } else {                                               // remainder chunks: plain order
+            const int r = b - nfull * tpc;
+            chunk = nfull + r / tpc;
+            tile = r % tpc;
+        }
+    }
     const int i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * BNW;
     long r0, r1;
     if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
