@@ -12,7 +12,7 @@ backward with gradients accumulating (run.py:178-191); the optimiser (RMSprop, r
 per epoch, here once at the end of the K timed steps, inside the timed region.
 
 N > 1: weak scaling, region-sharded.  The global graph has N*100k nodes and N*8 regions; rank g owns
-8 regions, all-gathers the packed boundary rows over RCCL every step and all-reduces the gradient
+8 regions, exchanges the packed halo rows over RCCL every step (all-to-all) and all-reduces the gradient
 buffer once before the optimiser step.  ``value`` counts 100k-node shard snapshots per second over all
 ranks (= N * steps / time).
 
@@ -152,7 +152,8 @@ def main():
         shard = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, gnodes, owner_bounds, region_owner,
                                    rank, world, dev)
         graph = shard.graph
-        xp_ext = torch.empty(shard.topo.x_rows, T, F, dtype=torch.float32, device=dev)
+        pipe = R.dist.HaloPipeline(shard, T, F, dev)
+        pipe.submit(0, xs[0])
     opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)   # run.py:145
     params = list(model.parameters())
     inv_count = 1.0 / float(gnodes * O)
@@ -162,11 +163,14 @@ def main():
         if shard is None:
             pred, _ = model.forward_prepared(x, graph)
         else:
-            _lib.check(lib.regt_pack_x(_lib.ptr(x), _lib.ptr(xp_ext), nodes, F, T, torch.cuda.current_stream().cuda_stream), "regt_pack_x")
-            R.dist.exchange_boundary_rows(xp_ext.view(shard.topo.x_rows, T * F), shard.topo, shard.send_idx)
+            # the halo rows of snapshot i were exchanged while step i-1 computed; start snapshot i+1's exchange now
+            xp_ext = pipe.acquire(i % 2)
+            pipe.submit((i + 1) % 2, xs[(i + 1) % n_snap])
             pred, _ = model.forward_packed(xp_ext, graph)
         loss = ((pred - y) ** 2).sum() * inv_count        # mean over the GLOBAL graph (run.py:180)
         loss.backward()
+        if shard is not None:
+            pipe.release(i % 2)
         return loss
 
     def epoch_end():
@@ -221,7 +225,7 @@ def main():
                                    f"per GPU, F={F}, T={T}, O={O}, hidden=256; RegionalTemporalGCN forward+MSE+backward per "
                                    "snapshot, RMSprop step once per K steps (run.py semantics)",
                        "global_nodes": gnodes, "global_edges": gedges, "global_regions": gregions,
-                       "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: boundary-row all-gather/step + 1 grad all-reduce",
+                       "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: halo-row all-to-all per step (one step ahead, side stream) + 1 grad all-reduce",
                        "final_loss": final_loss,
                        "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0},
         }

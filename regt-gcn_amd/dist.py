@@ -6,9 +6,9 @@ The reference is single-process; this layer is
   (GEMMs, gates, head, loss partial sums) and the regional ChebConv aggregation are local because
   regional edges never leave a region;
 * the only cross-rank dependency is the full-graph GCN aggregation ``A_hat x`` for in-edges whose
-  source lives on another rank.  ``x`` is input data, so ONE all-gather of the packed *boundary rows*
-  (nodes that have an out-edge into another shard) per snapshot suffices, and there is no sparse
-  backward traffic at all (A_hat x is constant w.r.t. the parameters);
+  source lives on another rank.  ``x`` is input data, so ONE exchange of packed *halo rows* per snapshot
+  suffices (a personalised all-to-all: each rank receives exactly the rows its in-edges read), and there
+  is no sparse backward traffic at all (A_hat x is constant w.r.t. the parameters);
 * gradients are summed with one flat-buffer all-reduce per optimiser step (the reference steps the
   optimiser once per epoch, run.py:194).
 
@@ -33,24 +33,39 @@ class ShardTopology:
     world: int
     node_lo: int
     node_hi: int
-    boundary: List[np.ndarray]     # per rank: sorted global ids of its boundary nodes
-    max_boundary: int
+    need: List[np.ndarray]         # need[s]: sorted global ids owned by rank s that in-edges of this rank read
+    send: List[np.ndarray]         # send[r]: sorted global ids owned by this rank that rank r reads (= r's need[rank])
 
     @property
     def n_local(self) -> int:
         return self.node_hi - self.node_lo
 
     @property
+    def halo_rows(self) -> int:
+        return int(sum(a.size for a in self.need))
+
+    @property
     def x_rows(self) -> int:
-        """Rows of the extended packed input: own nodes, then world * max_boundary gathered rows."""
-        return self.n_local + self.world * self.max_boundary
+        """Rows of the extended packed input: own nodes, then the halo rows grouped by owner rank."""
+        return self.n_local + self.halo_rows
+
+    @property
+    def recv_splits(self) -> List[int]:
+        return [int(a.size) for a in self.need]
+
+    @property
+    def send_splits(self) -> List[int]:
+        return [int(a.size) for a in self.send]
+
+    def halo_ids(self) -> np.ndarray:
+        """Global node id held by each halo row, in row order."""
+        return np.concatenate(self.need) if self.world > 1 else np.zeros(0, dtype=np.int64)
 
     def send_index(self) -> np.ndarray:
-        """Local row ids to send (own boundary nodes), padded with row 0 to max_boundary."""
-        idx = np.zeros(self.max_boundary, dtype=np.int64)
-        own = self.boundary[self.rank] - self.node_lo
-        idx[:own.size] = own
-        return idx
+        """Local row ids to send, grouped by destination rank."""
+        if self.world == 1:
+            return np.zeros(0, dtype=np.int64)
+        return np.concatenate(self.send) - self.node_lo
 
     def remap_columns(self, cols: np.ndarray, owner_bounds: np.ndarray) -> np.ndarray:
         """Global source ids -> row ids of the extended packed input of this rank."""
@@ -60,49 +75,87 @@ class ShardTopology:
         out[local] = cols[local] - self.node_lo
         rem = ~local
         if rem.any():
-            owner = np.searchsorted(owner_bounds, cols[rem], side="right") - 1
-            pos = np.empty(owner.size, dtype=np.int64)
-            for r in np.unique(owner):
-                m = owner == r
-                p = np.searchsorted(self.boundary[r], cols[rem][m])
-                if (p >= self.boundary[r].size).any() or (self.boundary[r][np.minimum(p, self.boundary[r].size - 1)] != cols[rem][m]).any():
-                    raise RuntimeError("halo source is not in its owner's boundary set")
-                pos[m] = p
-            out[rem] = self.n_local + owner * self.max_boundary + pos
+            halo = self.halo_ids()                  # ascending: owners are contiguous ranges in rank order
+            pos = np.searchsorted(halo, cols[rem])
+            if (pos >= halo.size).any() or (halo[np.minimum(pos, halo.size - 1)] != cols[rem]).any():
+                raise RuntimeError("halo source is not in this rank's need list")
+            out[rem] = self.n_local + pos
         return out
 
 
 def shard_topology(edge_index: np.ndarray, owner_bounds: np.ndarray, rank: int, world: int) -> ShardTopology:
-    """``owner_bounds`` (world+1,) contiguous node ownership; every rank computes the same boundary sets."""
+    """``owner_bounds`` (world+1,) contiguous node ownership.  Every rank derives the same (reader, owner)
+    lists from the global edge list, so send and receive sizes agree without a handshake."""
     src, dst = np.asarray(edge_index[0], dtype=np.int64), np.asarray(edge_index[1], dtype=np.int64)
     so = np.searchsorted(owner_bounds, src, side="right") - 1
     do = np.searchsorted(owner_bounds, dst, side="right") - 1
-    cross = (so != do) & (src != dst)
-    boundary = [np.unique(src[cross & (so == r)]) for r in range(world)]
-    mb = max(1, max(b.size for b in boundary))
-    return ShardTopology(rank, world, int(owner_bounds[rank]), int(owner_bounds[rank + 1]), boundary, mb)
+    empty = np.zeros(0, dtype=np.int64)
+    need = [np.unique(src[(do == rank) & (so == s)]) if s != rank else empty for s in range(world)]
+    send = [np.unique(src[(so == rank) & (do == r)]) if r != rank else empty for r in range(world)]
+    return ShardTopology(rank, world, int(owner_bounds[rank]), int(owner_bounds[rank + 1]), need, send)
 
 
 def exchange_boundary_rows(xp_ext: torch.Tensor, topo: ShardTopology, send_idx: torch.Tensor, group=None):
-    """All-gather the packed boundary rows into rows [n_local, x_rows) of ``xp_ext`` (in place).
+    """Fill rows [n_local, x_rows) of ``xp_ext`` (in place) with the halo rows, one all-to-all: every rank sends
+    each peer exactly the rows that peer's in-edges read.  xGMI is point-to-point, so the personalised exchange
+    maps onto the links directly and moves ~world x fewer bytes than all-gathering every boundary row to everyone.
 
     ``xp_ext``: (x_rows, W) with the rank's own packed rows already in [0, n_local).  Works with the
     'nccl' (RCCL) backend on GPU tensors and with 'gloo' on CPU tensors (tests)."""
     if topo.world == 1:
         return xp_ext
-    send = xp_ext.index_select(0, send_idx)                       # (max_boundary, W)
-    recv = xp_ext[topo.n_local:]                                   # (world*max_boundary, W), contiguous view
+    send = xp_ext.index_select(0, send_idx)                       # (sum send_splits, W)
+    recv = xp_ext[topo.n_local:]                                   # (halo_rows, W), contiguous view
     if xp_ext.is_cuda and dist.get_backend(group) == "gloo":
         # functional rehearsal of the multi-rank flow on a box without RCCL peers: stage through the host
-        host = [torch.empty(send.shape, dtype=send.dtype) for _ in range(topo.world)]
-        dist.all_gather(host, send.cpu(), group=group)
-        recv.copy_(torch.cat(host, dim=0))
-    elif xp_ext.is_cuda:
-        dist.all_gather_into_tensor(recv, send, group=group)
+        host = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(host, send.cpu(), topo.recv_splits, topo.send_splits, group=group)
+        recv.copy_(host)
     else:
-        parts = list(recv.view(topo.world, topo.max_boundary, -1).unbind(0))
-        dist.all_gather(parts, send, group=group)
+        dist.all_to_all_single(recv, send, topo.recv_splits, topo.send_splits, group=group)
     return xp_ext
+
+
+class HaloPipeline:
+    """Pack + halo exchange of snapshot i+1 on a side stream while the compute stream works on snapshot i.
+
+    The exchanged rows are input data (no dependence on the parameters), so the exchange can run a whole step
+    ahead; two extended input buffers alternate.  Usage per step::
+
+        buf = pipe.acquire(slot)            # compute stream waits for the slot's exchange
+        pipe.submit(1 - slot, x_next)       # side stream: pack x_next, all-to-all its halo rows
+        ... forward_packed(buf) / backward ...
+        pipe.release(slot)                  # the slot may be overwritten once this point is reached
+    """
+
+    def __init__(self, shard: "Shard", periods: int, features: int, device, group=None):
+        from . import ops
+        self._pack = ops.pack_x_into
+        self.shard, self.group = shard, group
+        self.T, self.F = periods, features
+        self.stream = torch.cuda.Stream(device)
+        rows = shard.topo.x_rows
+        self.buf = [torch.empty(rows, periods, features, dtype=torch.float32, device=device) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+        for e in self.free:
+            e.record(torch.cuda.current_stream(device))
+
+    def submit(self, slot: int, x: torch.Tensor):
+        topo = self.shard.topo
+        self.stream.wait_event(self.free[slot])
+        self.stream.wait_stream(torch.cuda.current_stream(x.device))      # x may have been produced just now
+        with torch.cuda.stream(self.stream):
+            self._pack(x, self.buf[slot])
+            exchange_boundary_rows(self.buf[slot].view(topo.x_rows, self.T * self.F), topo, self.shard.send_idx, self.group)
+            self.ready[slot].record(self.stream)
+
+    def acquire(self, slot: int) -> torch.Tensor:
+        torch.cuda.current_stream(self.buf[slot].device).wait_event(self.ready[slot])
+        return self.buf[slot]
+
+    def release(self, slot: int):
+        self.free[slot].record(torch.cuda.current_stream(self.buf[slot].device))
 
 
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
@@ -128,7 +181,7 @@ def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
 class Shard:
     topo: ShardTopology
     graph: PreparedGraph           # local stacked operator; A_hat columns index the extended input
-    send_idx: torch.Tensor         # (max_boundary,) int64 on the device
+    send_idx: torch.Tensor         # (sum send_splits,) int64 on the device
 
 
 def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], region_attr: Sequence[torch.Tensor],

@@ -28,6 +28,17 @@ def pack_x(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_x_into(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """(N,F,T) -> rows [0, N) of ``out`` (>= N rows of (T,F)); the remaining rows are left alone (halo slots)."""
+    x = _f32c(x, "x")
+    n, f, t = x.shape
+    if (out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device or out.dim() != 3
+            or out.shape[0] < n or tuple(out.shape[1:]) != (t, f)):
+        raise ValueError(f"pack_x_into: out must be a contiguous fp32 (>= {n}, {t}, {f}) tensor on {x.device}")
+    _lib.check(_lib.load().regt_pack_x(_lib.ptr(x), _lib.ptr(out), n, f, t, _stream()), "regt_pack_x")
+    return out
+
+
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None):
     """Y[r,:] = sum_e val[e] * X[col[e],:] for r in range(len(rowptr)-1)."""
     x = _f32c(x, "x")

@@ -36,10 +36,10 @@ def _worker(rank, world, port, n_per, e_per, regions_per, width, q):
         xp[:n_per] = x_glob[lo:hi]
         R.dist.exchange_boundary_rows(xp, topo, torch.from_numpy(topo.send_index()))
         # every halo slot holds the row of the node the topology says it holds
-        for r in range(world):
-            b = topo.boundary[r]
-            got = xp[n_per + r * topo.max_boundary: n_per + r * topo.max_boundary + b.size]
-            assert torch.equal(got, x_glob[torch.from_numpy(b)]), f"rank {rank}: halo rows of rank {r} wrong"
+        halo = topo.halo_ids()
+        assert halo.size == topo.halo_rows > 0 and np.all((halo < lo) | (halo >= hi))
+        assert torch.equal(xp[n_per:], x_glob[torch.from_numpy(halo)]), f"rank {rank}: halo rows wrong"
+        assert sum(topo.send_splits) == topo.send_index().size and topo.send_splits[rank] == 0
         # local rows of A_hat x computed from the extended input == rows of the global product
         src, dst, w = G.gcn_norm_edges(g.edge_index, None, n, torch.float32)
         want = G.propagate(src, dst, w, x_glob, n)[lo:hi]
@@ -56,14 +56,14 @@ def _worker(rank, world, port, n_per, e_per, regions_per, width, q):
         assert torch.equal(p[0].grad, torch.full((5, 3), float(tot)))
         assert torch.equal(p[1].grad, torch.arange(7, dtype=torch.float32) * tot)
         assert p[2].grad is None
-        q.put((rank, "ok", topo.max_boundary))
+        q.put((rank, "ok", (topo.send_splits, topo.recv_splits)))
     except Exception as e:  # noqa: BLE001
         q.put((rank, f"FAIL {type(e).__name__}: {e}", 0))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 3])
 def test_sharded_exchange_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -75,13 +75,16 @@ def test_sharded_exchange_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
-    assert res[0][2] == res[1][2] and res[0][2] > 1
+    by_rank = {r[0]: r[2] for r in res}
+    for a in range(world):
+        for b in range(world):
+            assert by_rank[a][0][b] == by_rank[b][1][a]            # what a sends to b is what b expects from a
 
 
 def test_topology_single_rank_has_no_halo():
     g = R.data.synthetic_regional_graph(300, 2000, 3, seed=1)
     topo = R.dist.shard_topology(g.edge_index.numpy(), np.array([0, 300]), 0, 1)
-    assert topo.boundary[0].size == 0 and topo.x_rows == 300 + 1
+    assert topo.halo_rows == 0 and topo.x_rows == 300 and topo.send_index().size == 0
     cols = topo.remap_columns(np.array([0, 5, 299]), np.array([0, 300]))
     assert cols.tolist() == [0, 5, 299]
 

@@ -205,7 +205,7 @@ def test_hidden_gradient_path(R, tpims):
 
 def test_region_sharded_path_matches_single_gpu(R):
     """Two region shards executed one after the other on the one GPU (halo rows copied by hand instead of
-    all-gathered): predictions, hidden rows and the summed gradients equal the unsharded run."""
+    exchanged): predictions, hidden rows and the summed gradients equal the unsharded run."""
     import numpy as np
     world, n_per, regions_per, f, t, o = 2, 1500, 3, 8, 6, 2
     n = n_per * world
@@ -230,8 +230,7 @@ def test_region_sharded_path_matches_single_gpu(R):
         lo, hi = sh.topo.node_lo, sh.topo.node_hi
         xp = torch.zeros(sh.topo.x_rows, t * f, device="cuda")
         xp[:n_per] = xp_glob[lo:hi]
-        for r, b in enumerate(sh.topo.boundary):
-            xp[n_per + r * sh.topo.max_boundary: n_per + r * sh.topo.max_boundary + b.size] = xp_glob[torch.from_numpy(b).cuda()]
+        xp[n_per:] = xp_glob[torch.from_numpy(sh.topo.halo_ids()).cuda()]
         pred, hid = shard_model.forward_packed(xp.view(sh.topo.x_rows, t, f), sh.graph)
         assert float((pred - pred_f[lo:hi]).abs().max()) < 1e-6
         assert float((hid - hid_f[lo:hi]).abs().max()) < 1e-6
