@@ -158,18 +158,25 @@ class HaloPipeline:
         self.free[slot].record(torch.cuda.current_stream(self.buf[slot].device))
 
 
+def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum all-reduce; a GPU tensor under the 'gloo' rehearsal backend is staged through the host."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
     """One flat-buffer sum all-reduce of all gradients (3-19 MB here: latency-bound on xGMI, so one call)."""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    if flat.is_cuda and dist.get_backend(group) == "gloo":
-        host = flat.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        flat.copy_(host)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = allreduce_sum(torch.cat([g.reshape(-1) for g in grads]), group)
     off = 0
     for g in grads:
         n = g.numel()

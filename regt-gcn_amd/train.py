@@ -23,7 +23,7 @@ import torch
 
 from . import nn as rnn
 from .data import snapshot_windows
-from .dist import allreduce_gradients
+from .dist import HaloPipeline, Shard, allreduce_gradients, allreduce_sum
 
 REGIONS = ("IA", "KS", "KY", "OH", "WI")
 
@@ -49,6 +49,49 @@ def evaluate(model, xs, ys, graph) -> Tuple[float, float]:
     model.eval()
     se = [(model.forward_prepared(x, graph)[0] - y) ** 2 for x, y in zip(xs, ys)]
     m = torch.cat(se, dim=0).mean()
+    return float(m.sqrt()), float(m)
+
+
+def train_epoch_sharded(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], shard: Shard, pipe: HaloPipeline,
+                        optimizer, global_nodes: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """train_epoch() for one region shard of a multi-GPU run: ``xs[i]`` (n_local, F, T) / ``ys[i]`` (n_local, O) are this
+    rank's rows of snapshot i.  The loss is the mean over the GLOBAL graph (run.py:180), so the per-rank partial sums are
+    scaled by 1/(global_nodes*O) before backward and the gradients of all ranks add up to the single-GPU gradient (one
+    flat all-reduce before the optimiser step).  Halo rows of snapshot i+1 travel while snapshot i computes.
+    Returns (last global loss, all global losses) as device tensors."""
+    model.train()
+    losses = []
+    if len(xs):
+        pipe.submit(0, xs[0])
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        buf = pipe.acquire(i % 2)
+        if i + 1 < len(xs):
+            pipe.submit((i + 1) % 2, xs[i + 1])
+        out, _ = model.forward_packed(buf, shard.graph)
+        loss = ((out - y) ** 2).sum() / float(global_nodes * y.shape[1])
+        loss.backward()
+        pipe.release(i % 2)
+        losses.append(loss.detach())
+    allreduce_gradients(list(model.parameters()), group)
+    tot = allreduce_sum(torch.stack(losses), group)
+    optimizer.step()
+    optimizer.zero_grad()
+    return tot[-1], tot
+
+
+@torch.no_grad()
+def evaluate_sharded(model, xs, ys, shard: Shard, pipe: HaloPipeline, global_nodes: int, group=None) -> Tuple[float, float]:
+    """run.py::test() over region shards: (rmse, mse) of the global graph."""
+    model.eval()
+    se = torch.zeros((), dtype=torch.float32, device=xs[0].device)
+    pipe.submit(0, xs[0])
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        buf = pipe.acquire(i % 2)
+        if i + 1 < len(xs):
+            pipe.submit((i + 1) % 2, xs[i + 1])
+        se += ((model.forward_packed(buf, shard.graph)[0] - y) ** 2).sum()
+        pipe.release(i % 2)
+    m = allreduce_sum(se, group) / float(global_nodes * ys[0].shape[1] * len(xs))
     return float(m.sqrt()), float(m)
 
 
