@@ -138,10 +138,12 @@ def main():
     model = R.RegionalTemporalGCN(node_features=F, num_nodes=nodes, periods=T, output_dim=O, num_regions=gregions)
     model = model.to(dev)
     n_snap = 4
-    snaps = R.data.synthetic_snapshots(gnodes, F, T, O, n_snap, seed=42)
-    lo, hi = rank * nodes, (rank + 1) * nodes
-    xs = [x[lo:hi].contiguous().to(dev) for x, _ in snaps]
-    ys = [y[lo:hi].contiguous().to(dev) for _, y in snaps]
+    # the global snapshot is the concatenation of per-rank row blocks, each drawn from its own seeded stream, so a rank
+    # only ever materialises its own 100k rows (8 ranks x the 800k-node tensor would be ~40 GB of host memory)
+    snaps = R.data.synthetic_snapshots(nodes, F, T, O, n_snap, seed=42 + 1000 * rank)
+    xs = [x.to(dev) for x, _ in snaps]
+    ys = [y.to(dev) for _, y in snaps]
+    del snaps
     if world == 1:
         graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index],
                                 [t.to(dev) for t in g.region_attr], nodes)
