@@ -154,18 +154,23 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
             }
         }
     }
-    reinterpret_cast<float4*>(Y)[row * W4 + panel * 8 + gl] = acc;
+    // streaming stores: the output is not read again here and must not evict the XCD's slice of X from its L2
+    float4* py = reinterpret_cast<float4*>(Y) + row * W4 + panel * 8 + gl;
+    __builtin_nontemporal_store(acc.x, &py->x); __builtin_nontemporal_store(acc.y, &py->y);
+    __builtin_nontemporal_store(acc.z, &py->z); __builtin_nontemporal_store(acc.w, &py->w);
 }
 
 // ---- dual-operator panel variant ----------------------------------------------------------------------
 // The regional Laplacian rows are (almost) a subset of the full-graph rows: the same neighbour row
 // x[col] feeds both A_hat x and L~ x.  With a merged CSR that carries two weights per entry, one gather
 // serves both outputs -- half the gather volume of the stacked operator.  Same XCD/panel schedule as above.
-template <int PL>   // lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two)
+template <int PL, int IDX, bool NTS>   // PL lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two);
+                                        // IDX (<= PL) CSR entries fetched per index load; NTS: streaming output stores
 __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                               const float* __restrict__ val_a, const float* __restrict__ val_l,
                                                               const float* __restrict__ X, float* __restrict__ YA,
                                                               float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb) {
+    static_assert(IDX % 8 == 0 && IDX <= PL, "index chunk is a multiple of the 8-gather round and fits the lane group");
     constexpr int ROWS = 256 / PL;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
     const int panel = li / nrb;
@@ -180,31 +185,48 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
     const float4* X4 = reinterpret_cast<const float4*>(X) + panel * PL + gl;
     float4 aa = make_float4(0.f, 0.f, 0.f, 0.f), al = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int base = beg; base < end; base += 8) {
-        const int n = end - base < 8 ? end - base : 8;
+    for (int base = beg; base < end; base += IDX) {
+        const int n = end - base < IDX ? end - base : IDX;
         int myc = 0;
         float mya = 0.f, myl = 0.f;
         if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
-        // all 8 gathers of the chunk in flight before the first FMA; entries >= n carry (col 0, weights 0)
-        float4 x[8];
-        float va[8], vl[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = __shfl(myc, e, PL);
-            va[e] = __shfl(mya, e, PL);
-            vl[e] = __shfl(myl, e, PL);
-            x[e] = e < n ? X4[(long)c * W4] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int r = 0; r < IDX / 8; ++r) {
+            if (r * 8 < n) {
+                // all 8 gathers of the round in flight before the first FMA; entries >= n carry (col 0, weights 0)
+                float4 x[8];
+                float va[8], vl[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            aa.x = fmaf(va[e], x[e].x, aa.x); aa.y = fmaf(va[e], x[e].y, aa.y);
-            aa.z = fmaf(va[e], x[e].z, aa.z); aa.w = fmaf(va[e], x[e].w, aa.w);
-            al.x = fmaf(vl[e], x[e].x, al.x); al.y = fmaf(vl[e], x[e].y, al.y);
-            al.z = fmaf(vl[e], x[e].z, al.z); al.w = fmaf(vl[e], x[e].w, al.w);
+                for (int e = 0; e < 8; ++e) {
+                    const int c = __shfl(myc, r * 8 + e, PL);
+                    va[e] = __shfl(mya, r * 8 + e, PL);
+                    vl[e] = __shfl(myl, r * 8 + e, PL);
+                    x[e] = r * 8 + e < n ? X4[(long)c * W4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    aa.x = fmaf(va[e], x[e].x, aa.x); aa.y = fmaf(va[e], x[e].y, aa.y);
+                    aa.z = fmaf(va[e], x[e].z, aa.z); aa.w = fmaf(va[e], x[e].w, aa.w);
+                    al.x = fmaf(vl[e], x[e].x, al.x); al.y = fmaf(vl[e], x[e].y, al.y);
+                    al.z = fmaf(vl[e], x[e].z, al.z); al.w = fmaf(vl[e], x[e].w, al.w);
+                }
+            }
         }
     }
-    reinterpret_cast<float4*>(YA)[row * W4 + panel * PL + gl] = aa;
-    reinterpret_cast<float4*>(YL)[row * W4 + panel * PL + gl] = al;
+    float4* pa = reinterpret_cast<float4*>(YA) + row * W4 + panel * PL + gl;
+    float4* pl = reinterpret_cast<float4*>(YL) + row * W4 + panel * PL + gl;
+    if (NTS) {
+        // the outputs are not read again by this kernel: streaming stores keep them from evicting the XCD's slice of X
+        // from its L2 (cfg-3, X resident in the Infinity Cache: 186 -> 149 us, L2 hits 64 -> 70 %; inside a training
+        // step, where X comes from HBM, 174 -> 167 us)
+        __builtin_nontemporal_store(aa.x, &pa->x); __builtin_nontemporal_store(aa.y, &pa->y);
+        __builtin_nontemporal_store(aa.z, &pa->z); __builtin_nontemporal_store(aa.w, &pa->w);
+        __builtin_nontemporal_store(al.x, &pl->x); __builtin_nontemporal_store(al.y, &pl->y);
+        __builtin_nontemporal_store(al.z, &pl->z); __builtin_nontemporal_store(al.w, &pl->w);
+    } else {
+        *pa = aa;
+        *pl = al;
+    }
 }
 
 int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
@@ -221,12 +243,21 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
     const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
     const long grid = 8L * npanels * nrb;
     REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual: grid too large");
-    if (wide)
-        hipLaunchKernelGGL(spmm_dual_panel_kernel<16>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL,
-                           nnodes, W4, npanels, nrb);
-    else
-        hipLaunchKernelGGL(spmm_dual_panel_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL,
-                           nnodes, W4, npanels, nrb);
+    static int nt_env = -1, idx_env = -1;
+    if (nt_env < 0) { const char* e = getenv("REGT_SPMM_NT"); nt_env = e ? atoi(e) : 1; }
+    if (idx_env < 0) { const char* e = getenv("REGT_SPMM_IDX"); idx_env = e ? atoi(e) : 16; }
+#define REGT_DUAL(PLL, IDXX, NTT)                                                                                              \
+    hipLaunchKernelGGL((spmm_dual_panel_kernel<PLL, IDXX, NTT>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, \
+                       X, YA, YL, nnodes, W4, npanels, nrb)
+    if (wide) {
+        if (nt_env == 0) REGT_DUAL(16, 8, false);
+        else if (idx_env == 8) REGT_DUAL(16, 8, true);
+        else REGT_DUAL(16, 16, true);
+    } else {
+        if (nt_env == 0) REGT_DUAL(8, 8, false);
+        else REGT_DUAL(8, 8, true);
+    }
+#undef REGT_DUAL
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

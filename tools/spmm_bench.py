@@ -16,11 +16,22 @@ def t(fn, n=30):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
+def t_cold(fn, n=15):
+    """each launch timed on its own after 1 GB of unrelated writes (what the kernel sees inside a training step)."""
+    junk = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+    tot = 0.0
+    for i in range(n + 3):
+        junk.fill_(float(i))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        if i >= 3: tot += e0.elapsed_time(e1)
+    return tot / n
 ya = torch.empty(nodes, W, device=dev); yl = torch.empty_like(ya)
 from regtgcn_amd import _lib
 lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
 dual = lambda: _lib.check(lib.regt_spmm_dual(_lib.ptr(pg.m_rowptr), _lib.ptr(pg.m_col), _lib.ptr(pg.m_val_a), _lib.ptr(pg.m_val_l), _lib.ptr(x), _lib.ptr(ya), _lib.ptr(yl), nodes, W, st), "dual")
 ms = t(dual)
+ms_cold = t_cold(dual)
 nnz = pg.m_col.numel()
 algo = nodes*W*4 + nnz*12 + (nodes+1)*4 + 2*nodes*W*4
-print(f"dual  PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}")
+print(f"dual  PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}   cold: {ms_cold*1e3:7.1f} us")
