@@ -188,6 +188,12 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
                       const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
                       const float* x_packed, void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* Arithmetic of the dense contractions.  0 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: every fp32 operand is
+ * split exactly into three bf16 pieces and the six leading partial products run on the bf16 MFMA with fp32
+ * accumulation -- fp32-level rounding error (dropped terms <= 3 * 2^-24 of a product), ~2x the matrix-pipe rate.
+ * Also selectable with REGT_GEMM_MODE=bf16x3 before the first call.  Returns the previous mode. */
+int32_t regt_set_gemm_mode(int32_t mode);
+
 /* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures).  collect() waits for the recorded events and writes "name count total_ms"
  * lines into buf. */

@@ -531,6 +531,12 @@ using namespace regt;
 extern "C" {
 
 int32_t regt_abi_version(void) { return REGT_ABI_VERSION; }
+
+int32_t regt_set_gemm_mode(int32_t mode) {
+    const int prev = gemm_mode();
+    set_gemm_mode(mode);
+    return prev;
+}
 const char* regt_last_error(void) { return g_err; }
 
 size_t regt_graph_workspace_bytes(int64_t E, int32_t N) { return graph_workspace_bytes((long)E, N); }

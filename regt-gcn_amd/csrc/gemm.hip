@@ -7,6 +7,7 @@
 //   small_gemm_kernel       strided batched C = A B for the (C x F)-sized weight compositions
 #include "kernels.h"
 #include "gemm_fast.h"
+#include "gemm_split.h"
 
 namespace regt {
 
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, i
 
 // Fast variant: straight-line K loop with interleaved loads (gemm_fast.h).  Requires vector-aligned
 // operands, one B layout for all segments and N % 4 == 0; everything else takes the generic kernel.
-template <class EpiF, bool BT, bool REGION>
+template <class EpiF, class Core>
 __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
     const long m0 = (long)(bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
-    FastCore<BT, REGION> core(S, rm, n0, N, lds);
+    Core core(S, rm, n0, N, lds);
     core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -186,6 +187,18 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
     core.run(acc, relu_a != 0);
     core.for_each_vec(acc, epi);
 }
+
+// 0: fp32 MFMA (default).  1: exact 3-way bf16 split of both operands, six partial products on the bf16 matrix pipe
+// (gemm_split.h) for the GEMMs whose B operand is stored [N][K].
+static int g_gemm_mode = -1;
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("REGT_GEMM_MODE");
+        g_gemm_mode = (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 0;
+    }
+    return g_gemm_mode;
+}
+void set_gemm_mode(int m) { g_gemm_mode = m ? 1 : 0; }
 
 // 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
 static int fast_class(const GemmSegs& S, int N, bool vec) {
@@ -212,16 +225,23 @@ static int fast_class(const GemmSegs& S, int N, bool vec) {
     return bt | (region << 1) | (relu << 2);
 }
 
-template <class EpiF, bool BT, bool REGION>
-static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
+template <class EpiF, class Core>
+static int launch_fast_core(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
     long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
     static bool attr_done = false;
-    if (int rc = set_lds_once(&gemm_flat_fast_kernel<EpiF, BT, REGION>, G_FAST_LDS_BYTES, &attr_done)) return rc;
-    hipLaunchKernelGGL((gemm_flat_fast_kernel<EpiF, BT, REGION>), dim3((unsigned)tiles), dim3(256), G_FAST_LDS_BYTES, st, S, M,
-                       N, f, relu);
+    if (int rc = set_lds_once(&gemm_flat_fast_kernel<EpiF, Core>, G_FAST_LDS_BYTES, &attr_done)) return rc;
+    hipLaunchKernelGGL((gemm_flat_fast_kernel<EpiF, Core>), dim3((unsigned)tiles), dim3(256), G_FAST_LDS_BYTES, st, S, M, N, f,
+                       relu);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
+}
+template <class EpiF, bool BT, bool REGION>
+static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
+    if constexpr (BT) {
+        if (gemm_mode() == 1) return launch_fast_core<EpiF, SplitCore<REGION>>(S, M, N, f, relu, st);
+    }
+    return launch_fast_core<EpiF, FastCore<BT, REGION>>(S, M, N, f, relu, st);
 }
 
 template <class EpiF>

@@ -1,0 +1,203 @@
+// fp32 GEMM on the bf16 matrix pipe: every fp32 operand element is split exactly into three bf16 pieces
+// (x = x1 + x2 + x3, 8 significant bits each -- bf16 has the fp32 exponent range, so the split never
+// under/overflows where fp32 does not) and the product is expanded into the six partial products whose
+// weight is >= 2^-16 of the leading one:
+//     a*b  ~=  a3 b1 + a2 b2 + a1 b3 + a2 b1 + a1 b2 + a1 b1           (dropped: a2 b3 + a3 b2 + a3 b3 <= 3 * 2^-24 |a b|)
+// Each bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result carries the same
+// order of rounding error as an fp32 FMA chain (the dropped terms are one fp32 ulp of the product), while
+// v_mfma_f32_32x32x16_bf16 retires 16x the k-extent of v_mfma_f32_32x32x2_f32 in half the cycles: 6 bf16 MFMAs
+// replace 8 fp32 MFMAs per 16 k and take 192 instead of 512 matrix-pipe cycles.
+//
+// Opt-in (regt_set_gemm_mode / REGT_GEMM_MODE=bf16x3); the default path stays on the fp32 MFMA (gemm_fast.h).
+//
+// Same 128x128 tile, 2x2 waves, row map, iteration table, buffer-descriptor loads and LDS-staged epilogue as
+// FastCore<true, REGION> (B given as [N][K], k contiguous).  What changes is the K loop:
+//   * LDS holds bf16 planes: stage h (h = 0, 1) = the h-th 16-k half of the current 32-k slab, per operand three
+//     planes of 128 rows x 32 B, k-group bit swizzled by row bit 3 (sp_off: conflict-free ds_read_b128 AND
+//     ds_write_b64 without padding).  2 stages x 24,576 B, inside the fp32 core's footprint, 2 workgroups per CU;
+//   * a thread owns 2 float4 of A and 2 of B per half (row = tid/4 (+64), k-quad = tid%4 (+4 for the second half)),
+//     splits them while storing (v_cvt_pk_bf16_f32 + packed fp32 subtract: 9 VALU per element pair);
+//   * the two halves double-buffer each other:  compute(h0) | barrier | store next h0 | compute(h1) | barrier |
+//     store next h1, so the conversion VALU work of one half overlaps the MFMAs of the other;
+//   * a half's registers are refilled with the same half of the slab after next as soon as they have been stored,
+//     i.e. every global load has two compute blocks of distance.
+#pragma once
+#include "gemm_fast.h"
+
+namespace regt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_ROW_B = 32;                   // bytes of one (row, plane) of a 16-k half slab: two 16-B k-groups, no pad
+constexpr int SP_PLANE_B = 128 * SP_ROW_B;     // 4096
+constexpr int SP_OPER_B = 3 * SP_PLANE_B;      // 12288: three planes of one operand
+constexpr int SP_STAGE_B = 2 * SP_OPER_B;      // 24576: A planes, then B planes
+static_assert(2 * SP_STAGE_B <= 2 * G_STAGE * 4, "split stages fit the fp32 core's LDS footprint (table offset, epilogue image)");
+// Byte offset of k-group g (8 k = 16 B) of row r inside a plane.  Rows are 32 B apart without padding; the k-group bit
+// is flipped for rows with bit 3 set, which makes both access patterns bank-conflict free (MI355X_MICROARCH.md, LDS):
+// ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) -- their 16 rows then fall
+// on 16 distinct 16-B bank quads; ds_write_b64 in 16 consecutive lanes = 4 rows x 4 k-quads = 32 distinct banks.
+__device__ __forceinline__ constexpr int sp_off(int r, int g) { return r * SP_ROW_B + ((g ^ ((r >> 3) & 1)) << 4); }
+
+template <bool REGION>
+struct SplitCore : FastCore<true, REGION> {
+    using Base = FastCore<true, REGION>;
+    using Srds = typename Base::Srds;
+    using Base::S;
+    using Base::rm;
+    using Base::n0;
+    using Base::N;
+    using Base::lds;
+    using Base::table;
+    using Base::nit;
+    using Base::tid;
+    using Base::lane;
+    using Base::wr;
+    using Base::wc;
+    int sreg[2];   // region of the thread's two staging rows (REGION only)
+
+    __device__ __forceinline__ SplitCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_) : Base(s, r, n0_, N_, lds_) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = (tid >> 2) + 64 * j;
+            sreg[j] = 0;
+            if (REGION && rl < rm.nvalid) sreg[j] = S.node_region[rm.grow(rl) / S.row_div];
+        }
+    }
+
+    // slot i of a thread: staging row (tid/4) + 64*(i/2), k-quad (tid%4) + 4*(i%2) of the 32-k slab -> half i%2
+    __device__ __forceinline__ float4 sload_a(const Srds& d, int i) const {
+        const int rl = (tid >> 2) + 64 * (i >> 1);
+        const int k = d.k0 + 4 * ((tid & 3) + 4 * (i & 1));
+        bool ok = rl < rm.nvalid && k < d.K;
+        if (REGION) ok = ok && (d.region < 0 || sreg[i >> 1] == d.region);
+        return Base::srd_load(d.a, ok ? 4u * (unsigned)(rl * (int)rm.mul * d.lda + k) : Base::SRD_OOB);
+    }
+    __device__ __forceinline__ float4 sload_b(const Srds& d, int i) const {
+        const int nl = (tid >> 2) + 64 * (i >> 1);
+        const int k = d.k0 + 4 * ((tid & 3) + 4 * (i & 1));
+        const bool ok = n0 + nl < N && k < d.K;
+        return Base::srd_load(d.b, ok ? 4u * (unsigned)(nl * d.ldb + k) : Base::SRD_OOB);
+    }
+
+    // exact 3-way bf16 split of four consecutive-k values, written to the three planes (8 B each)
+    __device__ __forceinline__ static void split_store(char* q, float4 v) {
+        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const bf16x2 bl = __builtin_convertvector(lo, bf16x2), bh = __builtin_convertvector(hi, bf16x2);
+            const unsigned ul = __builtin_bit_cast(unsigned, bl), uh = __builtin_bit_cast(unsigned, bh);
+            *reinterpret_cast<uint2*>(q + p * SP_PLANE_B) = make_uint2(ul, uh);
+            if (p < 2) {
+                const f32x2 fl = {__uint_as_float(ul << 16), __uint_as_float(ul & 0xffff0000u)};
+                const f32x2 fh = {__uint_as_float(uh << 16), __uint_as_float(uh & 0xffff0000u)};
+                lo -= fl;
+                hi -= fh;
+            }
+        }
+    }
+    // store the thread's slots of half h (slots h and h+2) of one register set
+    __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4], bool relu_a) const {
+        char* st = reinterpret_cast<char*>(lds) + h * SP_STAGE_B;
+        const float floor_a = relu_a ? 0.f : -__builtin_inff();     // branch-free relu: the K loop stays one basic block
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float4 a = ra[h + 2 * j];
+            a.x = fmaxf(a.x, floor_a); a.y = fmaxf(a.y, floor_a); a.z = fmaxf(a.z, floor_a); a.w = fmaxf(a.w, floor_a);
+            const int off = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
+            split_store(st + off, a);
+            split_store(st + SP_OPER_B + off, rb[h + 2 * j]);
+        }
+    }
+    // (re)load the thread's slots of half h (slots h and h+2) from slab `t`; `live` = false requests nothing (offsets
+    // beyond the descriptor range return 0 without touching memory) so that the K loop needs no branch
+    __device__ __forceinline__ void load_half(int h, const ItDesc& t, bool live, float4 (&ra)[4], float4 (&rb)[4]) const {
+        Srds d = Base::make_srds(t);
+        if (!live) d.K = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { ra[h + 2 * j] = sload_a(d, h + 2 * j); rb[h + 2 * j] = sload_b(d, h + 2 * j); }
+    }
+    // fragments of half h: three planes of two 32-row blocks per operand (12 x ds_read_b128)
+    struct Frags { bf16x8 a[2][3], b[2][3]; };
+    __device__ __forceinline__ Frags read_frags(int h) const {
+        const char* st = reinterpret_cast<const char*>(lds) + h * SP_STAGE_B;
+        const int lr = lane & 31, lh = lane >> 5;
+        Frags f;
+#pragma unroll
+        for (int p = 2; p >= 0; --p)             // plane 2 of A and plane 0 of B feed the first MFMAs
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f.a[t][p] = *reinterpret_cast<const bf16x8*>(st + p * SP_PLANE_B + sp_off(wr * 64 + t * 32 + lr, lh));
+                f.b[t][2 - p] = *reinterpret_cast<const bf16x8*>(st + SP_OPER_B + (2 - p) * SP_PLANE_B + sp_off(wc * 64 + t * 32 + lr, lh));
+            }
+        return f;
+    }
+    // acc += A_h x B_h^T over 16 k: 24 MFMAs (6 partial products x 4 tiles, the four accumulators round-robin)
+    __device__ __forceinline__ static void mfmas(const Frags& f, f32x16 (&acc)[2][2]) {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][PA[q]], f.b[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+    }
+    __device__ __forceinline__ void compute(int h, f32x16 (&acc)[2][2]) const { mfmas(read_frags(h), acc); }
+
+    // store half hs of the next slab while the MFMAs of half hc of the current slab run: one MFMA, then a few of the
+    // conversion VALU ops and now and then a plane write, so that a single wave keeps its SIMD's matrix pipe busy (a
+    // bf16 32x32x16 MFMA occupies the pipe for 32 cycles = 8 issue slots).  The registers just stored are refilled
+    // with the same half of the slab after next.
+    __device__ __forceinline__ void fused(int hs, int hc, const ItDesc& next, bool live, float4 (&ra)[4], float4 (&rb)[4],
+                                          f32x16 (&acc)[2][2], bool relu_a) const {
+        __builtin_amdgcn_sched_barrier(0);       // the interleaving pattern below applies to this block only
+        // fragment reads first in program order: the LDS writes below cannot be proven disjoint from them and would
+        // otherwise pin the reads (and with them every MFMA) behind the whole conversion
+        const Frags f = read_frags(hc);
+        store_half(hs, ra, rb, relu_a);
+        mfmas(f, acc);
+        load_half(hs, next, live, ra, rb);
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // all fragment reads
+#pragma unroll
+        for (int r = 0; r < 24; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (split arithmetic)
+            if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
+            if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // Schedule (slab it in LDS, slab it+1 in registers, the halves of slab it+2 requested as their registers free up):
+    //   C0(0) | { bar ; S0(it+1)+C1(it) ; bar ; S1(it+1)+C0(it+1) } ... | bar ; C1(last) ; bar
+    // stage 0 is rewritten only after the barrier that follows every wave's C0, stage 1 after the one that follows C1.
+    __device__ __forceinline__ void run(f32x16 (&acc)[2][2], bool relu_a) const {
+        if (nit == 0) return;
+        float4 ra[4], rb[4];
+        load_half(0, table[0], true, ra, rb);
+        load_half(1, table[0], true, ra, rb);
+        store_half(0, ra, rb, relu_a);
+        store_half(1, ra, rb, relu_a);
+        const bool two = nit > 1;
+        load_half(0, table[two ? 1 : 0], two, ra, rb);
+        load_half(1, table[two ? 1 : 0], two, ra, rb);
+        __syncthreads();
+        compute(0, acc);
+        for (int it = 0; it + 1 < nit; ++it) {
+            const bool live = it + 2 < nit;
+            const ItDesc& nx = table[live ? it + 2 : it + 1];
+            __syncthreads();
+            fused(0, 1, nx, live, ra, rb, acc, relu_a);
+            __syncthreads();
+            fused(1, 0, nx, live, ra, rb, acc, relu_a);
+        }
+        __syncthreads();
+        compute(1, acc);
+        __syncthreads();
+    }
+};
+
+}  // namespace regt

@@ -128,6 +128,10 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
                      float* YL, int nnodes, int W, hipStream_t st);   // YA = A x, YL = L x from one merged CSR (two weights/entry)
 
 // ---- cell backward head / small element-wise kernels -------------------------------------------
+// GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)
+int gemm_mode();
+void set_gemm_mode(int mode);
+
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {
     const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;
