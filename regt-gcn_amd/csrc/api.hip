@@ -152,6 +152,7 @@ struct Layout {
     float *A0, *Aall, *bprime, *Gzr, *Gh, *czr, *ch;
     // backward temporaries
     float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
+    float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r), bf16x3 split mode only
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
     int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
     size_t bytes;
@@ -183,6 +184,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.Gh = take(C * F);
     L.czr = take(2 * C);
     L.ch = take(C);
+    L.UT = take(3 * C * C);
     L.dOH = take(N * C);
     L.d1 = take(N * H1);
     L.dhp = take(M * C);
@@ -414,10 +416,17 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
     }
+    // The split core takes weights as [N][K] only: give the data gradients transposed copies of the three C x C blocks.
+    const bool split = gemm_mode() == 1;
+    if (split) {
+        PROF("transpose_gate_w", st);
+        TRY(launch_transpose3(p.gate_w[2] + C, p.gate_w[0] + C, p.gate_w[1] + C, 3, L.UT, C, C, 2L * C, st));
+    }
     {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
         GemmSegs S{};
         S.nseg = 1;
-        S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
+        if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true);
+        else S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad1 e{L.h, L.ZR, L.dOH, L.probs, L.dzr, L.dh, C, T};
         PROF("dgrad_candidate", st);
@@ -426,8 +435,13 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(L.dzr, 2L * C, p.gate_w[0] + C, nullptr, 2L * C, INT_MAX, C, false);
-        S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
+        if (split) {
+            S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true);
+            S.seg[1] = make_seg(L.dzr + C, 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true);
+        } else {
+            S.seg[0] = make_seg(L.dzr, 2L * C, p.gate_w[0] + C, nullptr, 2L * C, INT_MAX, C, false);
+            S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
+        }
         S.row_div = T;
         EpiDgrad2 e{L.dh, L.h, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
         PROF("dgrad_gates", st);

@@ -138,6 +138,30 @@ int launch_zero_f32(float* dst, long n, hipStream_t st) {
     return REGT_OK;
 }
 
+// dst[b] (cols x rows, ld = rows) = src[b]^T for up to three row-major (rows x cols, ld = lds) matrices: the
+// [K][N] -> [N][K] copies of the gate weights that the bf16x3 split GEMM core wants for the data gradients.
+__global__ __launch_bounds__(256) void transpose3_kernel(const float* s0, const float* s1, const float* s2, float* dst, int rows,
+                                                         int cols, long lds_) {
+    __shared__ float tile[32][33];
+    const float* src = blockIdx.z == 0 ? s0 : (blockIdx.z == 1 ? s1 : s2);
+    float* out = dst + (long)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(long)(r0 + i) * lds_ + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
+int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
+                      hipStream_t st) {
+    REGT_CHECK_ARG(count >= 1 && count <= 3 && rows > 0 && cols > 0, "transpose3: bad argument");
+    hipLaunchKernelGGL(transpose3_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32), count), dim3(256), 0, st, s0, s1, s2, dst, rows, cols, ld);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 // loss = scale * sum (pred - y)^2 ;  dpred = 2 * scale * (pred - y)     (scale = 1 / (N_global * O))
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* y, float* dpred, float* loss_out,
                                                        long n, float scale) {

@@ -276,12 +276,14 @@ int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipSt
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh);
+    if (fast_class(S, N, vec) == 1) return launch_fast<EpiDgrad1F, true, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad1F, false, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad1F{e}, vec, st);
 }
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.dh) && a16(e.h);
+    if (fast_class(S, N, vec) == 1) return launch_fast<EpiDgrad2F, true, false>(S, M, N, EpiDgrad2F{e}, 0, st);
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad2F, false, false>(S, M, N, EpiDgrad2F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad2F{e}, vec, st);
 }
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
 // that straddles two tiles (T <= 64 < 128, so never more than two) gets one partial sum from each,
 // added atomically into the zero-initialised hidden state -- two addends commute, so the result is
 // bit-reproducible.
+template <class Core>
 __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const long C = a.C, M = (long)a.num_nodes * a.T;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     const long m0 = (long)(bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     const RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
-    FastCore<true, false> core(a.S, rm, n0, a.C, lds);
+    Core core(a.S, rm, n0, a.C, lds);
     core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -430,13 +433,17 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias) &&
                      fast_class(a.S, a.C, true) == 1;
     if (vec) {
-        static bool attr_done = false;
-        if (int rc = set_lds_once(&gemm_cand_flat_kernel, G_FAST_LDS_BYTES, &attr_done)) return rc;
+        static bool attr_done = false, attr_done_split = false;
+        if (int rc = set_lds_once(&gemm_cand_flat_kernel<FastCore<true, false>>, G_FAST_LDS_BYTES, &attr_done)) return rc;
+        if (int rc = set_lds_once(&gemm_cand_flat_kernel<SplitCore<false>>, G_FAST_LDS_BYTES, &attr_done_split)) return rc;
         const long M = (long)a.num_nodes * a.T;
         const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
         REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
-        hipLaunchKernelGGL(gemm_cand_flat_kernel, dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        if (gemm_mode() == 1)
+            hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        else
+            hipLaunchKernelGGL((gemm_cand_flat_kernel<FastCore<true, false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
         static bool attr_done2 = false;
         if (int rc = set_lds_once(&gemm_cand_kernel<false>, G_LDS_BYTES, &attr_done2)) return rc;

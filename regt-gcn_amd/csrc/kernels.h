@@ -132,6 +132,8 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
 int gemm_mode();
 void set_gemm_mode(int mode);
 
+int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
+                      hipStream_t st);   // dst[b] = src[b]^T, b < count <= 3
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {
     const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;
