@@ -39,12 +39,13 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s is the measured achievable copy rate)
 
 # HBM bytes per launch of the dominant kernels at cfg-3 on one GPU, from rocprofv3 PMC passes of this same command
-# (profiles/r01_c_pmc_hbm_summary.txt): 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B/lane streaming reads --
+# (profiles/r01_d_pmc_hbm_summary.txt): 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B/lane streaming reads --
 # MI355X_MICROARCH.md, HBM section; calibrated here on cell_bwd, whose 3.7 GB of float4 reads show as 2.08e6 KB) + WRITE_SIZE.
 PMC_TRAFFIC_CFG3 = {
     "gemm_gates": 2 * 1.255e6 * 1024 + 3.600e6 * 1024,        # h (twice: A operand and R-half epilogue) + Âx; ZR + q written
     "dgrad_gates": 2 * 2.558e6 * 1024 + 1.200e6 * 1024,
     "wgrad_Uzr": 2 * 2.433e6 * 1024 + 3.564e4 * 1024,
+    "spmm": 2 * 2.055e5 * 1024 + 3.000e5 * 1024,              # profiles/r01_d_pmc_hbm_summary.txt (inside the step)
 }
 
 WORKLOADS = {
@@ -270,7 +271,8 @@ def main():
                 algo = x_rows * W * 4 + nnz * (12 if dual else 8) + (nodes + 1) * 4 * (1 if dual else 2) + 2 * nodes * W * 4
                 gbs = algo / (ms / c * 1e-3) / 1e9
                 out["roofline_spmm"] = {"kernel": "spmm_dual_panel (A_hat x and L~ x in one gather pass, width T*F)" if dual else "spmm_csr (stacked [A_hat; L~] x, width T*F)", "bound": "hbm", "achieved": gbs,
-                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                                        "traffic": PMC_TRAFFIC_CFG3["spmm"] if (args.workload == "cfg3" and world == 1 and dual) else None,
                                         "avg_ms": ms / c, "bytes_per_launch": algo}
             gemm_ms = sum(ms for k, (c, ms) in stages.items() if stage_flops(k, M, C, F))
             gemm_fl = sum(stage_flops(k, M, C, F) * c for k, (c, ms) in stages.items() if stage_flops(k, M, C, F))
