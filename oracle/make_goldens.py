@@ -18,6 +18,7 @@ Outputs (tests/golden/):
   golden_regt_ckpt.npz       G3  same with the reference's shipped checkpoint in6/out1
   golden_tgcn_*.npz          G4  TemporalGCN on the TPIMS fixture
   golden_loop.npz            G5  3-snapshot accumulate-then-RMSprop trajectory (run.py semantics)
+  golden_convstack_*.npz     G6  ConvStackedTemporalGCN on the TPIMS fixture
   ref_ckpt_in6_out1_epoch50.pt   data fixture: the checkpoint used by golden_regt_ckpt
 """
 from __future__ import annotations
@@ -100,6 +101,14 @@ def load_reference():
     from models.TemporalGCN import TemporalGCN  # noqa
     from models.utils import TGCN  # noqa
     return RegionalTemporalGCN, TemporalGCN, TGCN
+
+
+def load_reference_convstack():
+    install_standins()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.ConvStackedTemporalGCN import ConvStackedTemporalGCN  # noqa
+    return ConvStackedTemporalGCN
 
 
 # ---- helpers -------------------------------------------------------------------------------------
@@ -214,6 +223,26 @@ def golden_tgcn(TG, fx, t_in, t_out, seed, tag, window=0):
     np.savez_compressed(os.path.join(OUT, f"golden_tgcn_{tag}.npz"), **out)
 
 
+def golden_convstack(CS, fx, t_in, t_out, seed, tag, window=0):
+    """models/ConvStackedTemporalGCN.py on the TPIMS fixture, positional call of run.py:214."""
+    x = fx["node_data"][:, :, window:window + t_in].contiguous()
+    y = fx["node_data"][:, -1, window + t_in:window + t_in + t_out].contiguous()
+    mod = CS(node_features=8, periods=t_in, output_dim=t_out)
+    sd = omodel.init_params("ConvStackedTemporalGCN", 8, t_in, t_out, seed=seed)
+    res = mod.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    mod.zero_grad()
+    pred, hidden = mod(x, fx["edge_index"], fx["edge_attr"])
+    loss = torch.mean((pred - y) ** 2)
+    loss.backward()
+    grads = {n: p.grad for n, p in mod.named_parameters()}
+    out = {"t_in": t_in, "t_out": t_out, "seed": seed, "window": window, "pred": pred.detach().numpy(),
+           "hidden": hidden.detach().numpy(), "loss": np.array([float(loss)]), "param_checksum": param_checksum(sd)}
+    out.update(grads_summary(grads))
+    np.savez_compressed(os.path.join(OUT, f"golden_convstack_{tag}.npz"), **out)
+    return float(loss)
+
+
 def golden_loop(RegT, fx, t_in=6, t_out=1, seed=5, n_train=3, n_test=2, epochs=2):
     """run.py:163-226 semantics driven on the reference module: accumulate, one RMSprop step/epoch."""
     n = fx["node_data"].shape[0]
@@ -257,6 +286,9 @@ def main():
     for t_in, t_out, seed in ((6, 1, 6), (12, 3, 7)):
         golden_tgcn(TG, fx, t_in, t_out, seed, f"in{t_in}_out{t_out}")
     golden_loop(RegT, fx)
+    CS = load_reference_convstack()
+    for t_in, t_out, seed in ((6, 1, 8), (12, 3, 9)):
+        print("convstack", t_in, t_out, "loss", golden_convstack(CS, fx, t_in, t_out, seed, f"in{t_in}_out{t_out}"))
     print("goldens written to", OUT)
 
 

@@ -74,6 +74,31 @@ def a3tgcn(p: Params, x, edge_index, edge_weight, prefix="tgnn."):
     return acc
 
 
+CONVSTACK_HIDDEN = 512   # models/ConvStackedTemporalGCN.py:13
+CONVSTACK_HEAD_HIDDEN = 256   # models/ConvStackedTemporalGCN.py:16
+
+
+def conv_stacked_a3tgcn(p: Params, x, edge_index, edge_weight, prefix="tgnn."):
+    """models/ConvStackedTemporalGCN.py:115-126: five stacked GCNConv (no activation in between) on the weighted
+    full graph give the cell's hidden input; ``tgnn.linear`` (512*5 -> 512, :100) is never called."""
+    periods = x.shape[2]
+    probs = torch.softmax(p[f"{prefix}_attention"], dim=0)
+    acc = 0
+    for t in range(periods):
+        xt = x[:, :, t]
+        h = xt
+        for layer in range(1, 6):
+            h = gcn_conv(h, edge_index, edge_weight, p[f"{prefix}conv{layer}.lin.weight"], p[f"{prefix}conv{layer}.bias"])
+        acc = acc + probs[t] * tgcn_cell(p, f"{prefix}_base_tgcn.", xt, edge_index, edge_weight, h)
+    return acc
+
+
+def conv_stacked_temporal_gcn(p: Params, x, edge_index, edge_attr):
+    """ConvStackedTemporalGCN.forward -> (prediction (N,O), hidden (N,512))."""
+    hidden = conv_stacked_a3tgcn(p, x, edge_index, edge_attr)
+    return head(p, hidden), hidden
+
+
 def head(p: Params, hidden):
     """relu -> linear1 -> relu -> linear2 (models/RegionalTemporalGCN.py:35-38)."""
     y = torch.relu(hidden) @ p["linear1.weight"].t() + p["linear1.bias"]
@@ -117,6 +142,21 @@ def init_params(model: str, node_features: int, periods: int, output_dim: int, n
     C = hidden
     p: Params = {}
     p["tgnn._attention"] = torch.rand(periods, generator=g, dtype=dtype)
+    if model == "ConvStackedTemporalGCN":
+        C = CONVSTACK_HIDDEN if hidden == HIDDEN else hidden
+        for k in "zrh":
+            p[f"tgnn._base_tgcn.conv_{k}.bias"] = torch.randn(C, generator=g, dtype=dtype) * bias_scale
+            p[f"tgnn._base_tgcn.conv_{k}.lin.weight"] = _glorot(g, C, node_features, dtype)
+            w, b = _linear_init(g, C, 2 * C, dtype)
+            p[f"tgnn._base_tgcn.linear_{k}.weight"], p[f"tgnn._base_tgcn.linear_{k}.bias"] = w, b
+        for layer in range(1, 6):
+            p[f"tgnn.conv{layer}.bias"] = torch.randn(C, generator=g, dtype=dtype) * bias_scale
+            p[f"tgnn.conv{layer}.lin.weight"] = _glorot(g, C, node_features if layer == 1 else C, dtype)
+        p["tgnn.linear.weight"], p["tgnn.linear.bias"] = _linear_init(g, C, 5 * C, dtype)     # dead layer, :100
+        hh = CONVSTACK_HEAD_HIDDEN if hidden == HIDDEN else HEAD_HIDDEN
+        p["linear1.weight"], p["linear1.bias"] = _linear_init(g, hh, C, dtype)
+        p["linear2.weight"], p["linear2.bias"] = _linear_init(g, output_dim, hh, dtype)
+        return p
     if model == "RegionalTemporalGCN":
         assert num_nodes is not None
         p["tgnn._weight_att1"] = torch.randn(C, 1, generator=g, dtype=dtype) * 0.1
@@ -145,3 +185,4 @@ def init_params(model: str, node_features: int, periods: int, output_dim: int, n
 # parameters that never receive a gradient in the reference (dead code paths):
 UNUSED_PARAMS = ("tgnn._weight_att1", "tgnn._weight_att2", "tgnn._bias_att1", "tgnn._bias_att2")
 UNUSED_PARAMS_TEMPORAL = ("tgnn.linear.weight", "tgnn.linear.bias")
+UNUSED_PARAMS_CONVSTACK = ("tgnn.linear.weight", "tgnn.linear.bias")

@@ -75,6 +75,29 @@ def test_temporal_gcn_golden(tpims, tag):
         assert p[name].grad is None
 
 
+@pytest.mark.parametrize("tag", ["in6_out1", "in12_out3"])
+def test_conv_stacked_golden(tpims, tag):
+    """the oracle's ConvStackedTemporalGCN against the reference module's outputs."""
+    g = load_npz(f"golden_convstack_{tag}.npz")
+    t_in, t_out, w0 = int(g["t_in"]), int(g["t_out"]), int(g["window"])
+    p0 = M.init_params("ConvStackedTemporalGCN", 8, t_in, t_out, seed=int(g["seed"]))
+    chk = float(sum(v.double().abs().sum() for v in p0.values()))
+    assert abs(chk - float(g["param_checksum"][0])) < 1e-6 * chk, "seeded parameter stream drifted"
+    p = _leaf(p0)
+    x = tpims["node_data"][:, :, w0:w0 + t_in].contiguous()
+    y = tpims["node_data"][:, -1, w0 + t_in:w0 + t_in + t_out].contiguous()
+    pred, hidden = M.conv_stacked_temporal_gcn(p, x, tpims["edge_index"], tpims["edge_attr"])
+    assert hidden.shape == (x.shape[0], M.CONVSTACK_HIDDEN)
+    np.testing.assert_allclose(pred.detach().numpy(), g["pred"], atol=TOL)
+    np.testing.assert_allclose(hidden.detach().numpy(), g["hidden"], atol=TOL)
+    loss = torch.mean((pred - y) ** 2)
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-6
+    loss.backward()
+    check_grads_against_golden(g, {k: v.grad for k, v in p.items()}, atol=2e-6)
+    for name in M.UNUSED_PARAMS_CONVSTACK:
+        assert p[name].grad is None
+
+
 def test_loop_golden(tpims):
     g = load_npz("golden_loop.npz")
     t_in, t_out = int(g["t_in"]), int(g["t_out"])
