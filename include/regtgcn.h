@@ -188,6 +188,20 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
                       const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
                       const float* x_packed, void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* The part of the path every A3TGCN-style model of the reference shares -- TGCN cell (models/utils.py:163-203) over all
+ * periods, attention-weighted sum, relu/linear head -- on a hidden input the CALLER computed: h_in is (N*T, C), row
+ * node*T + t.  Replaces `self._base_tgcn(X[:, :, period], edge_index, edge_weight, h)` + head for models whose
+ * embedding stage is not the regional one, e.g. models/ConvStackedTemporalGCN.py:117-126 (five stacked GCNConv).
+ * dims.regional must be 0, dims.R is ignored (pass 1); graph needs rowptr/col/val of A_hat only (N rows, regt_gcn_csr);
+ * params/grads: cheb_* and region_* are not used.  Workspace: regt_workspace_bytes(dims, 0, 0).
+ * regt_cell_backward additionally returns dL/dh_in in dh_in (N*T, C). */
+int32_t regt_cell_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
+                          const float* h_in, float* pred, float* hidden, void* workspace, size_t workspace_bytes,
+                          regt_stream_t stream);
+int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
+                           const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
+                           const float* h_in, float* dh_in, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
 /* Arithmetic of the dense contractions.  0 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: every fp32 operand is
  * split exactly into three bf16 pieces and the six leading partial products run on the bf16 MFMA with fp32
  * accumulation -- fp32-level rounding error (dropped terms <= 3 * 2^-24 of a product), ~2x the matrix-pipe rate.

@@ -50,6 +50,8 @@ class Grads(C.Structure):
 SIGNATURES = {
     "regt_abi_version": (C.c_int32, []),
     "regt_set_gemm_mode": (C.c_int32, [C.c_int32]),
+    "regt_cell_forward": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_cell_backward": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_last_error": (C.c_char_p, []),
     "regt_graph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "regt_gcn_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),

@@ -281,10 +281,14 @@ int compose_forward(const regt_dims& d, const regt_params& p, const Layout& L, h
     return launch_small_gemm_multi(b, st);
 }
 
+// `h_ext` != NULL: the cell's hidden input (M x C, rows node*T + t) comes from the caller (regt_cell_forward); the
+// regional / Cheb embedding stage is skipped and only A_hat x is aggregated (graph = the N rows of A_hat).
 int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, const float* xp_ext,
-                 int x_rows, float* pred, float* hidden, const Layout& L, hipStream_t st, bool skip_pack = false) {
+                 int x_rows, float* pred, float* hidden, const Layout& L, hipStream_t st, bool skip_pack = false,
+                 const float* h_ext = nullptr) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
     const long M = (long)N * T;
+    const float* H = h_ext ? h_ext : L.h;
     {
         PROF("compose_fwd", st);
         TRY(launch_softmax_small(p.attention, L.probs, T, st));
@@ -298,7 +302,9 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     }
     {
         PROF("spmm", st);
-        if (g.overlap)
+        if (h_ext)
+            TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, N, xp_ext ? x_rows : N, T * F, 1, st));
+        else if (g.overlap)
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, (1 + R) * N, xp_ext ? x_rows : N, T * F, 1 + R, st));
         else if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
             TRY(launch_spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, T * F, st));
@@ -309,7 +315,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     const float* Aall = d.regional ? L.Aall : p.cheb_w1;
     const float* bpr = d.regional ? L.bprime : p.cheb_bias;
     // 2. regional embedding h = act(x A0^T + (L~ x) A_region^T + b')
-    {
+    if (!h_ext) {
         GemmSegs S{};
         S.nseg = 2;
         S.seg[0] = make_seg(Xp, F, A0, nullptr, F, INT_MAX, F, true);
@@ -328,10 +334,10 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(L.h, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true);
+        S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true);
         S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         S.row_div = T;
-        EpiGates e{L.ZR, L.h, L.q, L.czr, C};
+        EpiGates e{L.ZR, H, L.q, L.czr, C};
         PROF("gemm_gates", st);
         TRY(launch_gemm_gates(S, M, 2 * C, e, st));
     }
@@ -343,7 +349,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         a.S.seg[1] = make_seg(L.AX, F, L.Gh, nullptr, F, INT_MAX, F, true);
         a.S.row_div = T;
         a.num_nodes = N; a.T = T; a.C = C;
-        a.bias = L.ch; a.ZR = L.ZR; a.h = L.h; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
+        a.bias = L.ch; a.ZR = L.ZR; a.h = H; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
         PROF("gemm_candidate", st);
         TRY(launch_gemm_candidate(a, st));
     }
@@ -382,12 +388,16 @@ int wgrad_full(const char* name, const float* P, long ldp, int Nout, const float
     return launch_wgrad_reduce(r, st);
 }
 
+// `h_ext` / `dh_ext` != NULL (regt_cell_backward): the hidden input was supplied by the caller; its gradient is
+// written to dh_ext and the embedding-stage gradients (A0 / A_r / Cheb weights) are skipped.
 int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
                   const float* dpred, const float* dhidden, const float* hidden, const float* xp_ext, const Layout& L,
-                  hipStream_t st) {
+                  hipStream_t st, const float* h_ext = nullptr, float* dh_ext = nullptr) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
     const long M = (long)N * T;
     const float* Xp = xp_ext ? xp_ext : L.Xp;
+    const float* H = h_ext ? h_ext : L.h;
+    float* DH = dh_ext ? dh_ext : L.dh;
     // ---- head ----------------------------------------------------------------------------------
     TRY(wgrad_full("wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
     {   // d1 = (dpred A2) * (y1 > 0)
@@ -411,7 +421,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     }
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
-        CellBwdArgs a{L.dOH, L.probs, L.ZR, L.h, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
+        CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
         PROF("cell_bwd", st);
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
@@ -428,7 +438,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true);
         else S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
-        EpiDgrad1 e{L.h, L.ZR, L.dOH, L.probs, L.dzr, L.dh, C, T};
+        EpiDgrad1 e{H, L.ZR, L.dOH, L.probs, L.dzr, DH, C, T};
         PROF("dgrad_candidate", st);
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
     }
@@ -443,7 +453,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
         }
         S.row_div = T;
-        EpiDgrad2 e{L.dh, L.h, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        EpiDgrad2 e{DH, H, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
         PROF("dgrad_gates", st);
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
@@ -451,7 +461,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     TRY(wgrad_full("wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
     TRY(wgrad_full("wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, L.dGh, F, nullptr, st));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
-        WgradArgs a{L.dzr, 2L * C, 2 * C, L.h, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
+        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
         {
             PROF("wgrad_Uzr", st);
             TRY(launch_wgrad(a, st));
@@ -470,8 +480,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
-    TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dA0, F, dbpr, st));
-    if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
+    if (!h_ext) TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dA0, F, dbpr, st));
+    if (h_ext) {
+        // no embedding stage behind a caller-supplied hidden input
+    } else if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
         for (int r = 0; r < R; ++r)
             TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab,
                            dAall + (long)r * C * F, F, nullptr, st));
@@ -528,11 +540,12 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     return REGT_OK;
 }
 
-int check_ptrs(const regt_params* p, const regt_dims& d) {
+int check_ptrs(const regt_params* p, const regt_dims& d, bool cell_only = false) {
     REGT_CHECK_ARG(p != nullptr, "params is NULL");
-    bool ok = p->attention && p->cheb_w0 && p->cheb_w1 && p->cheb_bias && p->head1_w && p->head1_b && p->head2_w && p->head2_b;
+    bool ok = p->attention && p->head1_w && p->head1_b && p->head2_w && p->head2_b;
+    if (!cell_only) ok = ok && p->cheb_w0 && p->cheb_w1 && p->cheb_bias;
     for (int k = 0; k < 3; ++k) ok = ok && p->conv_lin_w[k] && p->conv_bias[k] && p->gate_w[k] && p->gate_b[k];
-    if (d.regional) ok = ok && p->region_w && p->region_b;
+    if (d.regional && !cell_only) ok = ok && p->region_w && p->region_b;
     REGT_CHECK_ARG(ok, "params: a required tensor pointer is NULL");
     return REGT_OK;
 }
@@ -710,6 +723,40 @@ int32_t regt_graph_stats(int64_t* out) {
     out[0] = g_fwd_graphs.eager; out[1] = g_fwd_graphs.captured; out[2] = g_fwd_graphs.replayed;
     out[3] = g_bwd_graphs.eager; out[4] = g_bwd_graphs.captured; out[5] = g_bwd_graphs.replayed;
     return REGT_OK;
+}
+
+/* ---- TGCN cell + attention + head on a caller-supplied hidden input (regtgcn.h) --------------------------------- */
+int32_t regt_cell_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
+                          const float* h_in, float* pred, float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+    TRY(check_dims(dims));
+    REGT_CHECK_ARG(dims->regional == 0, "regt_cell_forward: dims.regional must be 0");
+    REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && !graph->overlap, "regt_cell_forward: graph incomplete");
+    TRY(check_ptrs(params, *dims, true));
+    REGT_CHECK_ARG(x && h_in && pred && hidden && ws, "regt_cell_forward: NULL pointer");
+    REGT_CHECK_ARG(al16(x) && al16(h_in) && al16(hidden) && al16(ws), "regt_cell_forward: x, h_in, hidden and workspace must be 16-byte aligned");
+    Layout L = make_layout(*dims, 0, 0, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    return forward_impl(*dims, *graph, *params, x, nullptr, 0, pred, hidden, L, (hipStream_t)st, false, h_in);
+}
+
+int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const regt_grads* grads,
+                           const float* dpred, const float* dhidden, const float* hidden, const float* h_in, float* dh_in,
+                           void* ws, size_t ws_bytes, regt_stream_t st) {
+    TRY(check_dims(dims));
+    REGT_CHECK_ARG(dims->regional == 0, "regt_cell_backward: dims.regional must be 0");
+    REGT_CHECK_ARG(graph && graph->rowptr && !graph->overlap, "regt_cell_backward: graph incomplete");
+    TRY(check_ptrs(params, *dims, true));
+    REGT_CHECK_ARG(grads && dpred && hidden && h_in && dh_in && ws, "regt_cell_backward: NULL pointer");
+    REGT_CHECK_ARG(al16(h_in) && al16(dh_in), "regt_cell_backward: h_in and dh_in must be 16-byte aligned");
+    {
+        const regt_grads& g = *grads;
+        bool ok = g.head1_w && g.head1_b && g.head2_w && g.head2_b;
+        for (int k = 0; k < 3; ++k) ok = ok && g.conv_lin_w[k] && g.conv_bias[k] && g.gate_w[k] && g.gate_b[k];
+        REGT_CHECK_ARG(ok, "regt_cell_backward: a required gradient pointer is NULL (only `attention` may be NULL)");
+    }
+    Layout L = make_layout(*dims, 0, 0, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, nullptr, L, (hipStream_t)st, h_in, dh_in);
 }
 
 int32_t regt_profile_enable(int32_t on) {

@@ -41,11 +41,11 @@ int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st
 template <int G, int CH>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ X,
-                                                       float* __restrict__ Y, int nrows, int nrows_x, int W4) {
+                                                       float* __restrict__ Y, int nrows, int nrows_x, int W4, int ld4) {
     constexpr int GROUPS = 256 / G;
     const int gl = threadIdx.x % G;                // lane inside the group
     const int gid = threadIdx.x / G;
-    const long W = (long)W4 * 4;
+    const long W = (long)ld4 * 4;                  // row stride of X and Y; W4 = float4 columns handled by this launch
     for (long row = (long)blockIdx.x * GROUPS + gid; row < nrows; row += (long)gridDim.x * GROUPS) {
         float4 acc[CH];
 #pragma unroll
@@ -264,12 +264,12 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
 
 template <int G, int CH>
 static int launch_spmm_t(const int* rowptr, const int* col, const float* val, const float* X, float* Y, int nrows,
-                         int nrows_x, int W4, hipStream_t st) {
+                         int nrows_x, int W4, int ld4, hipStream_t st) {
     constexpr int GROUPS = 256 / G;
     long blocks = ((long)nrows + GROUPS - 1) / GROUPS;
     if (blocks > 256L * 64) blocks = 256L * 64;
     hipLaunchKernelGGL((spmm_csr_kernel<G, CH>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val, X, Y, nrows,
-                       nrows_x, W4);
+                       nrows_x, W4, ld4);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -292,7 +292,15 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
         REGT_CHECK_LAUNCH();
         return REGT_OK;
     }
-#define REGT_SPMM(G, CH) return launch_spmm_t<G, CH>(rowptr, col, val, X, Y, nrows, nrows_x, W4, st)
+    // rows wider than 2048 floats (hidden-state aggregation of the stacked-conv baseline: T * 512): column passes
+    if (W4 > 512) {
+        for (int c4 = 0; c4 < W4; c4 += 512) {
+            const int w4 = W4 - c4 < 512 ? W4 - c4 : 512;
+            if (int rc = launch_spmm_t<64, 8>(rowptr, col, val, X + 4L * c4, Y + 4L * c4, nrows, nrows_x, w4, W4, st)) return rc;
+        }
+        return REGT_OK;
+    }
+#define REGT_SPMM(G, CH) return launch_spmm_t<G, CH>(rowptr, col, val, X, Y, nrows, nrows_x, W4, W4, st)
     if (W4 <= 8) REGT_SPMM(8, 1);
     if (W4 <= 16) REGT_SPMM(16, 1);
     if (W4 <= 32) REGT_SPMM(32, 1);
@@ -303,7 +311,7 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
     if (W4 <= 256) REGT_SPMM(64, 4);
     if (W4 <= 512) REGT_SPMM(64, 8);
 #undef REGT_SPMM
-    set_error("spmm: row width %d floats not supported (max 2048)", W);
+    set_error("spmm: row width %d floats not supported", W);
     return REGT_ERR_ARG;
 }
 

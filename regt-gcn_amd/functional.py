@@ -190,6 +190,117 @@ class RegTGCNFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
 
 
+# ---- models whose embedding stage is not the regional one: cell on a caller-supplied hidden input ---------------------
+
+PARAM_NAMES_CELL = (
+    ["tgnn._attention"]
+    + [f"tgnn._base_tgcn.conv_{k}.lin.weight" for k in GATES]
+    + [f"tgnn._base_tgcn.conv_{k}.bias" for k in GATES]
+    + [f"tgnn._base_tgcn.linear_{k}.weight" for k in GATES]
+    + [f"tgnn._base_tgcn.linear_{k}.bias" for k in GATES]
+    + PARAM_NAMES_HEAD
+)
+
+
+def _gcn_graph_struct(op) -> _lib.Graph:
+    g = _lib.Graph()
+    g.rowptr, g.col, g.val = op.rowptr.data_ptr(), op.col.data_ptr(), op.val.data_ptr()
+    return g
+
+
+class CellFunction(torch.autograd.Function):
+    """(x (N,F,T), h_in (N*T, C), *cell params) -> (pred (N,O), hidden (N,C)): regt_cell_forward / regt_cell_backward."""
+
+    @staticmethod
+    def forward(ctx, x, h_in, op, *params):
+        lib = _lib.load()
+        if not x.is_cuda:
+            raise _lib.RegtError("RegT-GCN forward needs CUDA/HIP tensors: there is no CPU path in this package")
+        names = PARAM_NAMES_CELL
+        if len(params) != len(names):
+            raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
+        x, h_in = x.contiguous(), h_in.contiguous()
+        N, F, T = x.shape
+        tens = dict(zip(names, params))
+        Cdim = tens["tgnn._base_tgcn.conv_z.bias"].numel()
+        O, H1 = tens["linear2.weight"].shape[0], tens["linear1.weight"].shape[0]
+        if tuple(h_in.shape) != (N * T, Cdim) or h_in.dtype != torch.float32:
+            raise ValueError(f"h_in must be float32 ({N * T}, {Cdim}), got {h_in.dtype} {tuple(h_in.shape)}")
+        if N != op.num_nodes:
+            raise ValueError(f"x has {N} nodes but the prepared operator has {op.num_nodes}")
+        dims = _lib.Dims(N, T, F, Cdim, 1, O, H1, 0, 0.0)
+        gs = _gcn_graph_struct(op)
+        wsb = lib.regt_workspace_bytes(C.byref(dims), 0, 0)
+        if wsb == 0:
+            _lib.check(1, "regt_workspace_bytes")
+        handle = _WsHandle(_POOL.acquire(wsb, x.device))
+        pred = torch.empty(N, O, dtype=torch.float32, device=x.device)
+        hidden = torch.empty(N, Cdim, dtype=torch.float32, device=x.device)
+        ps = _fill(_lib.Params(), tens, False)
+        _lib.check(lib.regt_cell_forward(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), _lib.ptr(h_in), _lib.ptr(pred),
+                                         _lib.ptr(hidden), _lib.ptr(handle.ws), wsb, _stream()), "regt_cell_forward")
+        ctx.op, ctx.dims, ctx.ws_handle, ctx.wsb = op, dims, handle, wsb
+        ctx.save_for_backward(hidden, h_in, *params)
+        return pred, hidden
+
+    @staticmethod
+    def backward(ctx, dpred, dhidden):
+        lib = _lib.load()
+        hidden, h_in, *params = ctx.saved_tensors
+        names, dims = PARAM_NAMES_CELL, ctx.dims
+        tens = dict(zip(names, params))
+        dev = hidden.device
+        if dpred is None:
+            dpred = torch.zeros(dims.N, dims.O, dtype=torch.float32, device=dev)
+        dpred = dpred.contiguous()
+        dhid = None if dhidden is None else dhidden.contiguous()
+        grads = {n_: torch.empty_like(p_) for n_, p_ in tens.items()}
+        dh_in = torch.empty_like(h_in)
+        gs = _gcn_graph_struct(ctx.op)
+        ps = _fill(_lib.Params(), tens, False)
+        gr = _fill(_lib.Grads(), grads, False)
+        _lib.check(lib.regt_cell_backward(C.byref(dims), C.byref(gs), C.byref(ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
+                                          _lib.ptr(hidden), _lib.ptr(h_in), _lib.ptr(dh_in), _lib.ptr(ctx.ws_handle.ws), ctx.wsb,
+                                          _stream()), "regt_cell_backward")
+        return (None, dh_in, None) + tuple(grads[n_] for n_ in names)
+
+
+class AggregateFunction(torch.autograd.Function):
+    """Y = A_hat @ H for a learned H (N, W): forward pulls over the CSR of A_hat, backward over the CSR of A_hat^T."""
+
+    @staticmethod
+    def forward(ctx, h, op):
+        from . import ops
+        ctx.op = op
+        return ops.spmm_csr(op.rowptr, op.col, op.val, h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        op = ctx.op
+        return ops.spmm_csr(op.t_rowptr, op.t_col, op.t_val, dy.contiguous()), None
+
+
+class LinearFunction(torch.autograd.Function):
+    """y = a @ w.T + b on the matrix cores; backward: da = dy @ w, (dw, db) = wgrad(dy, a)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b):
+        from . import ops
+        ctx.save_for_backward(a, w)
+        ctx.need_da = a.requires_grad
+        return ops.linear(a, w, b, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        a, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        da = ops.linear(dy, w.t().contiguous(), None, 0) if ctx.need_da else None
+        dw, db = ops.wgrad(dy, a)
+        return da, dw, db
+
+
 def regt_gcn_forward(x, graph: PreparedGraph, params: Dict[str, torch.Tensor], regional: bool = True, slope: float = 0.01):
     """Functional entry: ``params`` keyed by the reference's state_dict names."""
     names = param_names(regional)

@@ -213,6 +213,40 @@ def merge_operators(rp_a, col_a, val_a, rp_l, col_l, val_l, num_nodes: int):
     return rowptr.contiguous(), m_col.contiguous(), va.contiguous(), vl.contiguous()
 
 
+@dataclass
+class GcnOperator:
+    """A_hat of one static graph as a destination-sorted CSR, plus the CSR of its transpose (the backward of
+    ``A_hat @ H`` w.r.t. a learned H is ``A_hat^T @ dY``; A_hat is symmetric only for symmetric edge lists)."""
+    num_nodes: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    val: torch.Tensor
+    t_rowptr: torch.Tensor
+    t_col: torch.Tensor
+    t_val: torch.Tensor
+
+
+def transpose_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, num_rows: int, num_cols: int):
+    """CSR of the transposed operator (index bookkeeping on the device, once per graph).  Entries of one output row
+    are ordered by their original row id, so the summation order of the transposed SpMM is fixed too."""
+    dev = rowptr.device
+    rows = torch.repeat_interleave(torch.arange(num_rows, device=dev), (rowptr[1:] - rowptr[:-1]).long())
+    key = col.long() * num_rows + rows                       # sort by (col, row)
+    order = torch.argsort(key, stable=True)
+    t_col = rows[order].to(torch.int32)
+    t_val = val[order].contiguous()
+    counts = torch.bincount(col.long(), minlength=num_cols)
+    t_rowptr = torch.zeros(num_cols + 1, dtype=torch.int32, device=dev)
+    t_rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return t_rowptr.contiguous(), t_col.contiguous(), t_val
+
+
+def prepare_gcn_operator(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> GcnOperator:
+    rp, col, val = gcn_csr(edge_index, edge_weight, num_nodes)
+    t = transpose_csr(rp, col, val, num_nodes, num_nodes)
+    return GcnOperator(num_nodes, rp, col, val, t[0], t[1], t[2])
+
+
 def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], region_index: Sequence[torch.Tensor],
                   region_weight: Sequence[Optional[torch.Tensor]], num_nodes: int) -> PreparedGraph:
     """Build the stacked [A_hat; L~] operator.

@@ -6,6 +6,7 @@ unchanged:
 
 * :class:`RegionalTemporalGCN`  <-> models/RegionalTemporalGCN.py:9-39  (+ RegionalA3TGCN :42-149)
 * :class:`TemporalGCN`          <-> models/TemporalGCN.py:7-32          (+ A3TGCN :35-91)
+* :class:`ConvStackedTemporalGCN` <-> models/ConvStackedTemporalGCN.py:8-33 (+ ConvStackedA3TGCN :35-126)
 * :class:`TGCN`                 <-> models/utils.py:69-203 (parameter container of the GRU cell)
 
 The modules only *hold* parameters; all arithmetic runs in libregtgcn_hip.so through
@@ -21,8 +22,10 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .functional import HEAD_HIDDEN, RegTGCNFunction, param_names
-from .graph import PreparedGraph, fingerprint, prepare_graph
+from . import ops
+from .functional import (HEAD_HIDDEN, PARAM_NAMES_CELL, AggregateFunction, CellFunction, LinearFunction, RegTGCNFunction,
+                         param_names)
+from .graph import GcnOperator, PreparedGraph, fingerprint, prepare_gcn_operator, prepare_graph
 
 HIDDEN = 256          # out_channels=256, models/RegionalTemporalGCN.py:14 / models/TemporalGCN.py:12
 LEAKY_SLOPE = 0.01    # F.leaky_relu default, models/RegionalTemporalGCN.py:143
@@ -231,3 +234,69 @@ class TemporalGCN(_FusedModel):
         n = x.shape[0]
         graph = self._graphs.get([edge_index, edge_attr], n, lambda: prepare_graph(edge_index, edge_attr, [edge_index], [edge_attr], n))
         return self._run(x, graph)
+
+
+class ConvStackedA3TGCN(nn.Module):
+    """Parameter layout of models/ConvStackedTemporalGCN.py:35-103: TGCN cell, five GCNConv, a never-called
+    ``linear`` (512*5 -> 512, :100) and the attention over periods."""
+
+    def __init__(self, in_channels: int, out_channels: int, periods: int, improved: bool = False, cached: bool = False,
+                 add_self_loops: bool = True):
+        super().__init__()
+        if improved or not add_self_loops:
+            raise NotImplementedError("only improved=False, add_self_loops=True is on the hot path")
+        self.in_channels, self.out_channels, self.periods = in_channels, out_channels, periods
+        self._base_tgcn = TGCN(in_channels=in_channels, out_channels=out_channels)
+        self.conv1 = _GCNConvParams(in_channels, out_channels)
+        self.conv2 = _GCNConvParams(out_channels, out_channels)
+        self.conv3 = _GCNConvParams(out_channels, out_channels)
+        self.conv4 = _GCNConvParams(out_channels, out_channels)
+        self.conv5 = _GCNConvParams(out_channels, out_channels)
+        self.linear = nn.Linear(out_channels * 5, out_channels)      # dead layer of the reference, kept for state_dict parity
+        self._attention = nn.Parameter(torch.empty(periods))
+        nn.init.uniform_(self._attention)
+
+
+class ConvStackedTemporalGCN(nn.Module):
+    """Stacked-GCNConv baseline.  ``forward(x, edge_index, edge_attr)`` ->
+    ``(prediction (N, output_dim), hidden (N, 512))`` (models/ConvStackedTemporalGCN.py:21-33).
+
+    Per period the reference runs conv1..conv5 = A_hat (h W^T) + b without activation and feeds the result to the TGCN
+    cell as its hidden input.  Here all periods go through each layer at once on node-major rows (node*T + t):
+    layer 1 aggregates the *input* (width T*F, no sparse backward), layers 2-5 aggregate the learned hidden state at
+    width T*512 with the CSR of A_hat forward and of A_hat^T backward; the dense parts are fp32-MFMA GEMMs and the
+    cell + attention + head is ``regt_cell_forward`` / ``regt_cell_backward``."""
+
+    HIDDEN = 512          # models/ConvStackedTemporalGCN.py:13
+    HEAD = 256            # :16
+
+    def __init__(self, node_features: int, periods: int, output_dim: int):
+        super().__init__()
+        self.tgnn = ConvStackedA3TGCN(in_channels=node_features, out_channels=self.HIDDEN, periods=periods)
+        self.linear1 = nn.Linear(self.HIDDEN, self.HEAD)
+        self.linear2 = nn.Linear(self.HEAD, output_dim)
+        self.relu = nn.ReLU()
+        self.output_dim = output_dim
+        self._graphs = _GraphCache()
+
+    def prepare_graph(self, edge_index, edge_attr, num_nodes: int) -> GcnOperator:
+        return prepare_gcn_operator(edge_index, edge_attr, num_nodes)
+
+    def forward_prepared(self, x: torch.Tensor, op: GcnOperator):
+        _need_cuda(x)
+        n, f, t = x.shape
+        c = self.HIDDEN
+        sd = dict(self.named_parameters())
+        xp = ops.pack_x(x)                                                      # (N, T, F)
+        ax = ops.spmm_csr(op.rowptr, op.col, op.val, xp.view(n, t * f))          # A_hat x: input data, no backward
+        h = LinearFunction.apply(ax.view(n * t, f), sd["tgnn.conv1.lin.weight"], sd["tgnn.conv1.bias"])
+        for layer in range(2, 6):
+            s = AggregateFunction.apply(h.view(n, t * c), op)
+            h = LinearFunction.apply(s.view(n * t, c), sd[f"tgnn.conv{layer}.lin.weight"], sd[f"tgnn.conv{layer}.bias"])
+        return CellFunction.apply(x, h, op, *[sd[k] for k in PARAM_NAMES_CELL])
+
+    def forward(self, x, edge_index, edge_attr):
+        _need_cuda(x)
+        n = x.shape[0]
+        op = self._graphs.get([edge_index, edge_attr], n, lambda: prepare_gcn_operator(edge_index, edge_attr, n))
+        return self.forward_prepared(x, op)
