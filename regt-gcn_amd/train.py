@@ -109,7 +109,7 @@ def main(argv=None):
     ap.add_argument("--tr", "--train_ratio", default=0.8, type=float, dest="tr")
     ap.add_argument("--num_timesteps_in", default=8, type=int)
     ap.add_argument("--num_timesteps_out", default=4, type=int)
-    ap.add_argument("--model", default="RegionalTemporalGCN", choices=["RegionalTemporalGCN", "TemporalGCN"])
+    ap.add_argument("--model", default="RegionalTemporalGCN", choices=["RegionalTemporalGCN", "TemporalGCN", "ConvStackedTemporalGCN"])
     ap.add_argument("--fixture", required=True, help=".npz with node_data (N,F,steps), edge_index, edge_attr, edge_<R>_index/attr")
     ap.add_argument("--out_dir", default="pretrained")
     ap.add_argument("--is_pretrained", action="store_true")
@@ -129,8 +129,11 @@ def main(argv=None):
         model = rnn.RegionalTemporalGCN(f, n, a.num_timesteps_in, a.num_timesteps_out).to(dev)
         graph = model.prepare_graph(ei, [torch.from_numpy(d[f"edge_{r}_index"]).to(dev) for r in REGIONS],
                                     [torch.from_numpy(d[f"edge_{r}_attr"]).to(dev) for r in REGIONS])
-    else:
+    elif a.model == "TemporalGCN":
         model = rnn.TemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
+        graph = model.prepare_graph(ei, torch.from_numpy(d["edge_attr"]).to(dev), n)
+    else:                                                                   # run.py:125-126
+        model = rnn.ConvStackedTemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
         graph = model.prepare_graph(ei, torch.from_numpy(d["edge_attr"]).to(dev), n)
     if a.is_pretrained:
         model.load_state_dict(torch.load(a.pretrained_model, map_location=dev, weights_only=True))
