@@ -632,6 +632,194 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum;
 }
 
+// ---- weight gradients on the bf16 matrix pipe (opt-in bf16x3 split, gemm_split.h) ---------------------------
+// Same tile (128 x 128), chunking, slab output and XCD mapping as wgrad_kernel<128>; the K loop follows SplitCore:
+// P and Q rows are split exactly into three bf16 planes while they are staged, two 16-row half slabs double-buffer
+// each other, six partial products per tile pair.  The operands lie k-major in HBM (row m contiguous along i) and are
+// staged exactly so: a [16 m][128 i] bf16 image per plane with 256-byte rows whose 16-byte chunks are XOR-swizzled
+// (image (b) of cdna_hip_programming.md T10) -- conflict-free for the ds_write_b64 of the staging pass and for
+// ds_read_b64_tr_b16, the transposing LDS read that hands every lane 4 consecutive k of one column: two of them per
+// plane make the 8-k operand of v_mfma_f32_32x32x16_bf16 without any shuffle.
+constexpr int WS_PLANE_B = 16 * 256;             // one plane of one operand of one half slab
+constexpr int WS_OPER_B = 3 * WS_PLANE_B;        // 12288
+constexpr int WS_STAGE_B = 2 * WS_OPER_B;        // 24576: P planes, then Q planes
+constexpr int WS_LDS_BYTES = 2 * WS_STAGE_B;     // 49152
+__device__ __forceinline__ int ws_off(int m, int ch) { return 256 * m + 16 * (ch ^ (((m & 3) << 2) | ((m >> 2) & 3))); }
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
+    using Core = FastCore<true, false>;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_i = (a.Nout + 127) / 128, tiles_j = (a.Nin + 127) / 128;
+    const int tpc = tiles_i * tiles_j;
+    int tile, chunk;
+    {   // all tiles of one row chunk on the same XCD (see wgrad_kernel)
+        const int nfull = (a.nchunks / 8) * 8;
+        const int b = blockIdx.x;
+        if (b < nfull * tpc) {
+            const int xcd = b & 7, li = b >> 3;
+            chunk = (li / tpc) * 8 + xcd;
+            tile = li % tpc;
+        } else {
+            const int r = b - nfull * tpc;
+            chunk = nfull + r / tpc;
+            tile = r % tpc;
+        }
+    }
+    const int i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * 128;
+    long r0, r1;
+    if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
+    else { r0 = (long)chunk * a.kchunk; r1 = r0 + a.kchunk < a.M ? r0 + a.kchunk : a.M; }
+    const int nrows = (int)(r1 - r0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the thread's 4 columns of P over its rows
+    const bool do_csum = a.colsum && j0 == 0;
+
+    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(a.P + r0 * a.ldp + i0);
+    const __amdgpu_buffer_rsrc_t sq = Core::make_srd(a.Q + r0 * a.ldq + j0);
+    const int ldp = (int)a.ldp, ldq = (int)a.ldq;
+    const int c4 = tid & 31;                             // the thread's float4 column (4 i's) in both tiles
+    const bool okp = i0 + 4 * c4 < a.Nout, okq = j0 + 4 * c4 < a.Nin;
+    const float qfloor = a.q_relu ? 0.f : -__builtin_inff();
+
+    // slot s of a thread: half h = s & 1, row 16 h + (tid >> 5) + 8 (s >> 1) of the 32-row slab
+    auto load_half = [&](int h, int k0, bool live, float4 (&rp)[4], float4 (&rq)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = k0 + 16 * h + (tid >> 5) + 8 * j;
+            const bool ok = live && m < nrows;
+            rp[h + 2 * j] = Core::srd_load(sp, ok && okp ? 4u * (unsigned)(m * ldp + 4 * c4) : Core::SRD_OOB);
+            rq[h + 2 * j] = Core::srd_load(sq, ok && okq ? 4u * (unsigned)(m * ldq + 4 * c4) : Core::SRD_OOB);
+        }
+    };
+    auto store_half = [&](int h, const float4 (&rp)[4], const float4 (&rq)[4]) {
+        char* st = ldsb + h * WS_STAGE_B;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 p = rp[h + 2 * j];
+            float4 q = rq[h + 2 * j];
+            q.x = fmaxf(q.x, qfloor); q.y = fmaxf(q.y, qfloor); q.z = fmaxf(q.z, qfloor); q.w = fmaxf(q.w, qfloor);
+            csum.x += p.x; csum.y += p.y; csum.z += p.z; csum.w += p.w;
+            const int off = ws_off((tid >> 5) + 8 * j, c4 >> 1) + 8 * (c4 & 1);
+            SplitCore<false>::split_store(st + off, p, WS_PLANE_B);
+            SplitCore<false>::split_store(st + WS_OPER_B + off, q, WS_PLANE_B);
+        }
+    };
+    struct Frags { bf16x8 a[2][3], b[2][3]; };
+    // lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3; the group receives 4 k x 16 columns
+    // transposed.  Groups 0,1 take columns 0-15 / 16-31 of the 32-column tile at k = 0..3, groups 2,3 the same
+    // columns at k = 8..11; a second read 4 rows further down completes the 8-k operand.
+    const int gq = (lane >> 2) & 3, gp = lane & 3, gg = lane >> 4;
+    auto read_frags = [&](int h) {
+        const char* st = ldsb + h * WS_STAGE_B;
+        Frags f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int ca = (wr * 64 + t * 32 + 16 * (gg & 1) + 4 * gp) >> 3;      // 16-byte chunk of the lane's 4 columns
+            const int cb = (wc * 64 + t * 32 + 16 * (gg & 1) + 4 * gp) >> 3;
+            const int sub = 8 * (gp & 1);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                s16x4 lo, hi;
+                const int m0 = 8 * (gg >> 1) + gq;
+                lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + p * WS_PLANE_B + ws_off(m0, ca) + sub));
+                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + p * WS_PLANE_B + ws_off(m0 + 4, ca) + sub));
+                f.a[t][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + WS_OPER_B + p * WS_PLANE_B + ws_off(m0, cb) + sub));
+                hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + WS_OPER_B + p * WS_PLANE_B + ws_off(m0 + 4, cb) + sub));
+                f.b[t][p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+        return f;
+    };
+    auto mfmas = [&](const Frags& f) {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi][PA[q]], f.b[ni][PB[q]], acc[mi][ni], 0, 0, 0);
+    };
+    auto fused = [&](int hs, int hc, int k_next, bool live, float4 (&rp)[4], float4 (&rq)[4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        const Frags f = read_frags(hc);
+        store_half(hs, rp, rq);
+        mfmas(f);
+        load_half(hs, k_next, live, rp, rq);
+        __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+#pragma unroll
+        for (int r = 0; r < 24; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nit = (nrows + 31) / 32;
+    if (nit > 0) {
+        float4 rp[4], rq[4];
+        load_half(0, 0, true, rp, rq);
+        load_half(1, 0, true, rp, rq);
+        store_half(0, rp, rq);
+        store_half(1, rp, rq);
+        load_half(0, 32, nit > 1, rp, rq);
+        load_half(1, 32, nit > 1, rp, rq);
+        __syncthreads();
+        mfmas(read_frags(0));
+        for (int it = 0; it + 1 < nit; ++it) {
+            const bool live = it + 2 < nit;
+            __syncthreads();
+            fused(0, 1, (it + 2) * 32, live, rp, rq);
+            __syncthreads();
+            fused(1, 0, (it + 2) * 32, live, rp, rq);
+        }
+        __syncthreads();
+        mfmas(read_frags(1));
+    }
+    const long stride = (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0);
+    float* out = a.slab + (long)chunk * stride;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            int i = i0 + wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (i < a.Nout) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    int j = j0 + wc * 64 + ni * 32 + lr;
+                    if (j < a.Nin) out[(long)i * a.Nin + j] = acc[mi][ni][reg];
+                }
+            }
+        }
+    if (do_csum) {      // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fixed-order reduction through LDS
+        __syncthreads();
+        reinterpret_cast<float4*>(lds)[tid] = csum;
+        __syncthreads();
+        if (tid < 128 && i0 + tid < a.Nout) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += lds[(g * 32 + (tid >> 2)) * 4 + (tid & 3)];
+            out[(long)a.Nout * a.Nin + i0 + tid] = s;
+        }
+    }
+}
+
 // Generic fallback (scalar-guarded loads) for operands that are not 16-byte tileable, e.g. the (N, O) head gradient.
 template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
 __global__ __launch_bounds__(256, 2) void wgrad_kernel_generic(WgradArgs a) {
@@ -763,8 +951,11 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     const bool fast = a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.Nout % 4 == 0 && a.Nin % 4 == 0 && a16(a.P) && a16(a.Q) &&
                       a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536);
     if (wide) {
-        static bool attr_done = false, attr_done_g = false;
-        if (fast) {
+        static bool attr_done = false, attr_done_g = false, attr_done_s = false;
+        if (fast && gemm_mode() == 1) {
+            if (int rc = set_lds_once(&wgrad_split_kernel, WS_LDS_BYTES, &attr_done_s)) return rc;
+            hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)blocks), dim3(256), WS_LDS_BYTES, st, a);
+        } else if (fast) {
             if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
             hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
         } else {

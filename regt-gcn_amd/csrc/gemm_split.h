@@ -83,13 +83,13 @@ struct SplitCore : FastCore<true, REGION> {
     }
 
     // exact 3-way bf16 split of four consecutive-k values, written to the three planes (8 B each)
-    __device__ __forceinline__ static void split_store(char* q, float4 v) {
+    __device__ __forceinline__ static void split_store(char* q, float4 v, int plane_stride = SP_PLANE_B) {
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const bf16x2 bl = __builtin_convertvector(lo, bf16x2), bh = __builtin_convertvector(hi, bf16x2);
             const unsigned ul = __builtin_bit_cast(unsigned, bl), uh = __builtin_bit_cast(unsigned, bh);
-            *reinterpret_cast<uint2*>(q + p * SP_PLANE_B) = make_uint2(ul, uh);
+            *reinterpret_cast<uint2*>(q + p * plane_stride) = make_uint2(ul, uh);
             if (p < 2) {
                 const f32x2 fl = {__uint_as_float(ul << 16), __uint_as_float(ul & 0xffff0000u)};
                 const f32x2 fh = {__uint_as_float(uh << 16), __uint_as_float(uh & 0xffff0000u)};
