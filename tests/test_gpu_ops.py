@@ -96,11 +96,12 @@ def test_spmm_panel_variant_large_graph(R):
     n, e, width = 41003, 300000, 160
     ei, w = _rand_graph(n, e, 9)
     rp, col, val = R.graph.gcn_csr(ei.cuda(), w.cuda(), n)
-    x = torch.randn(n, width)
+    x = torch.randn(n, width, generator=torch.Generator().manual_seed(9))
     got = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
-    s, d, wn = G.gcn_norm_edges(ei, w, n, torch.float32)
-    want = G.propagate(s, d, wn, x, n)
-    assert float((got - want).abs().max()) < 2e-6
+    s, d, wn = G.gcn_norm_edges(ei, w, n, torch.float64)
+    want = G.propagate(s, d, wn, x.double(), n)
+    # fp32 sums in edge order vs float64: a few ulp of the largest row sum
+    assert float((got.double() - want).abs().max()) < 4e-6 * max(1.0, float(want.abs().max()) / 8)
     again = R.ops.spmm_csr(rp, col, val, x.cuda()).cpu()
     assert torch.equal(got, again)
 
