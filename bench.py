@@ -282,8 +282,8 @@ def main():
         if split_dt is not None:
             out["opt_in_bf16x3_split"] = {
                 "value": args.steps / split_dt, "unit": "snapshots/s", "ms_per_step": 1e3 * split_dt / args.steps,
-                "note": "REGT_GEMM_MODE=bf16x3: gate/candidate/regional GEMMs and their data gradients as 6 bf16 partial products of "
-                        "an exact 3-way bf16 split, fp32 accumulate; weight gradients still fp32 MFMA; passes the same parity suite; "
+                "note": "REGT_GEMM_MODE=bf16x3: gate/candidate/regional GEMMs, their data gradients and the wide weight gradients as "
+                        "6 bf16 partial products of an exact 3-way bf16 split, fp32 accumulate; passes the same parity suite; "
                         "NOT the headline value"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, edges, regions, F, T, O)
