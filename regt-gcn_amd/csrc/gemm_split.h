@@ -99,13 +99,13 @@ struct SplitCore : FastCore<true, REGION> {
         }
     }
     // store the thread's slots of half h (slots h and h+2) of one register set
-    __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4], bool relu_a) const {
+    template <bool RELU>
+    __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4]) const {
         char* st = reinterpret_cast<char*>(lds) + h * SP_STAGE_B;
-        const float floor_a = relu_a ? 0.f : -__builtin_inff();     // branch-free relu: the K loop stays one basic block
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 a = ra[h + 2 * j];
-            a.x = fmaxf(a.x, floor_a); a.y = fmaxf(a.y, floor_a); a.z = fmaxf(a.z, floor_a); a.w = fmaxf(a.w, floor_a);
+            if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             const int off = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
             split_store(st + off, a);
             split_store(st + SP_OPER_B + off, rb[h + 2 * j]);
@@ -113,9 +113,12 @@ struct SplitCore : FastCore<true, REGION> {
     }
     // (re)load the thread's slots of half h (slots h and h+2) from slab `t`; `live` = false requests nothing (offsets
     // beyond the descriptor range return 0 without touching memory) so that the K loop needs no branch
-    __device__ __forceinline__ void load_half(int h, const ItDesc& t, bool live, float4 (&ra)[4], float4 (&rb)[4]) const {
+    __device__ __forceinline__ Srds slab_srds(const ItDesc& t, bool live) const {
         Srds d = Base::make_srds(t);
         if (!live) d.K = 0;
+        return d;
+    }
+    __device__ __forceinline__ void load_half(int h, const Srds& d, float4 (&ra)[4], float4 (&rb)[4]) const {
 #pragma unroll
         for (int j = 0; j < 2; ++j) { ra[h + 2 * j] = sload_a(d, h + 2 * j); rb[h + 2 * j] = sload_b(d, h + 2 * j); }
     }
@@ -151,15 +154,15 @@ struct SplitCore : FastCore<true, REGION> {
     // conversion VALU ops and now and then a plane write, so that a single wave keeps its SIMD's matrix pipe busy (a
     // bf16 32x32x16 MFMA occupies the pipe for 32 cycles = 8 issue slots).  The registers just stored are refilled
     // with the same half of the slab after next.
-    __device__ __forceinline__ void fused(int hs, int hc, const ItDesc& next, bool live, float4 (&ra)[4], float4 (&rb)[4],
-                                          f32x16 (&acc)[2][2], bool relu_a) const {
+    template <bool RELU>
+    __device__ __forceinline__ void fused(int hs, int hc, const Srds& next, float4 (&ra)[4], float4 (&rb)[4], f32x16 (&acc)[2][2]) const {
         __builtin_amdgcn_sched_barrier(0);       // the interleaving pattern below applies to this block only
         // fragment reads first in program order: the LDS writes below cannot be proven disjoint from them and would
         // otherwise pin the reads (and with them every MFMA) behind the whole conversion
         const Frags f = read_frags(hc);
-        store_half(hs, ra, rb, relu_a);
+        store_half<RELU>(hs, ra, rb);
         mfmas(f, acc);
-        load_half(hs, next, live, ra, rb);
+        load_half(hs, next, ra, rb);
         __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // all fragment reads
 #pragma unroll
         for (int r = 0; r < 24; ++r) {
@@ -174,29 +177,40 @@ struct SplitCore : FastCore<true, REGION> {
     // Schedule (slab it in LDS, slab it+1 in registers, the halves of slab it+2 requested as their registers free up):
     //   C0(0) | { bar ; S0(it+1)+C1(it) ; bar ; S1(it+1)+C0(it+1) } ... | bar ; C1(last) ; bar
     // stage 0 is rewritten only after the barrier that follows every wave's C0, stage 1 after the one that follows C1.
-    __device__ __forceinline__ void run(f32x16 (&acc)[2][2], bool relu_a) const {
-        if (nit == 0) return;
+    template <bool RELU>
+    __device__ __forceinline__ void run_t(f32x16 (&acc)[2][2]) const {
         float4 ra[4], rb[4];
-        load_half(0, table[0], true, ra, rb);
-        load_half(1, table[0], true, ra, rb);
-        store_half(0, ra, rb, relu_a);
-        store_half(1, ra, rb, relu_a);
-        const bool two = nit > 1;
-        load_half(0, table[two ? 1 : 0], two, ra, rb);
-        load_half(1, table[two ? 1 : 0], two, ra, rb);
+        {
+            const Srds d = slab_srds(table[0], true);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+        }
+        store_half<RELU>(0, ra, rb);
+        store_half<RELU>(1, ra, rb);
+        {
+            const bool two = nit > 1;
+            const Srds d = slab_srds(table[two ? 1 : 0], two);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+        }
         __syncthreads();
         compute(0, acc);
         for (int it = 0; it + 1 < nit; ++it) {
             const bool live = it + 2 < nit;
-            const ItDesc& nx = table[live ? it + 2 : it + 1];
+            const Srds nx = slab_srds(table[live ? it + 2 : it + 1], live);      // once per slab, shared by both halves
             __syncthreads();
-            fused(0, 1, nx, live, ra, rb, acc, relu_a);
+            fused<RELU>(0, 1, nx, ra, rb, acc);
             __syncthreads();
-            fused(1, 0, nx, live, ra, rb, acc, relu_a);
+            fused<RELU>(1, 0, nx, ra, rb, acc);
         }
         __syncthreads();
         compute(1, acc);
         __syncthreads();
+    }
+    __device__ __forceinline__ void run(f32x16 (&acc)[2][2], bool relu_a) const {
+        if (nit == 0) return;
+        if (relu_a) run_t<true>(acc);            // head only: relu on A while staging
+        else run_t<false>(acc);
     }
 };
 
