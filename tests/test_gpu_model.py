@@ -294,3 +294,31 @@ def test_cpu_tensors_are_refused(R):
     mod = R.RegionalTemporalGCN(8, 10, 6, 1)
     with pytest.raises(R.RegtError):
         mod(torch.zeros(10, 8, 6), torch.zeros(2, 0, dtype=torch.long))
+
+
+@pytest.mark.parametrize("hidden,mode", [(64, 0), (132, 0), (132, 1), (320, 1)])
+def test_other_hidden_widths_match_oracle(R, hidden, mode):
+    """The reference fixes C = 256; the kernels do not (column tiles that are partial, K loops that end mid-slab)."""
+    n, e, regions, f, t, o = 500, 4000, 3, 8, 5, 2
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=hidden)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(2))
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=4, hidden=hidden)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    pred_o, hid_o = M.regional_temporal_gcn(po, x, ei, ri, rw)
+    torch.mean((pred_o - y) ** 2).backward()
+    lib = R.load_library()
+    prev = lib.regt_set_gemm_mode(mode)
+    try:
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions, hidden_channels=hidden)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        pred, hidden_out = mod(x.cuda(), ei.cuda(), _cuda_list(ri), _cuda_list(rw))
+        torch.mean((pred - y.cuda()) ** 2).backward()
+    finally:
+        lib.regt_set_gemm_mode(prev)
+    assert float((pred.detach().cpu() - pred_o.detach()).abs().max()) < TOL
+    assert float((hidden_out.detach().cpu() - hid_o.detach()).abs().max()) < TOL
+    for k, q in mod.named_parameters():
+        if k in M.UNUSED_PARAMS:
+            continue
+        np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=TOL, rtol=1e-4, err_msg=k)
