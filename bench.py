@@ -11,10 +11,11 @@ A "step" is what the reference's run.py::train() does per snapshot: forward, mea
 backward with gradients accumulating (run.py:178-191); the optimiser (RMSprop, run.py:145) steps once
 per epoch, here once at the end of the K timed steps, inside the timed region.
 
-N > 1: weak scaling, region-sharded.  The global graph has N*100k nodes and N*8 regions; rank g owns
-8 regions, exchanges the packed halo rows over RCCL every step (all-to-all) and all-reduces the gradient
-buffer once before the optimiser step.  ``value`` counts 100k-node shard snapshots per second over all
-ranks (= N * steps / time).
+N > 1: weak scaling, region-sharded (BASELINE.json configs[4] shape of growth).  The global graph has N*100k nodes and
+N*8 regions; rank g owns 8 regions, exchanges the packed halo rows over RCCL every step (all-to-all, one step ahead on
+a side stream) and all-reduces the gradient buffer once before the optimiser step.  ``value`` counts 100k-node shard
+snapshots per second over all ranks (= N * steps / time).  ``--scaling strong`` instead splits the ONE 100k-node graph by
+regions (configs[3]: 8 regions, one per GPU at N = 8); ``value`` is then whole-graph snapshots per second.
 
 The JSON line carries ``roofline`` (dominant kernel, measured with HIP events recorded on the launch
 stream by the library itself: regt_profile_*) and ``cpu_baseline`` (the oracle's eager-faithful CPU
@@ -61,6 +62,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU owns a full workload-sized shard (global graph N times larger, the default "
+                         "the driver measures); strong = the ONE workload graph split by regions across the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3-split measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
@@ -132,9 +136,18 @@ def main():
     from regtgcn_amd import _lib
     lib = R.load_library()
 
-    # ---- data: global graph of world*cfg shape, this rank's shard ------------------------------------
-    gnodes, gedges, gregions = nodes * world, edges * world, regions * world
+    # ---- data: global graph (weak: world x the workload shape; strong: the workload itself), this rank's shard ------
+    weak = args.scaling == "weak" or world == 1
+    if weak:
+        gnodes, gedges, gregions = nodes * world, edges * world, regions * world
+    else:
+        if regions % world:
+            raise SystemExit(f"--scaling strong needs the {regions} regions to divide evenly over {world} GPUs")
+        gnodes, gedges, gregions = nodes, edges, regions
     g = R.data.synthetic_regional_graph(gnodes, gedges, gregions, seed=42)
+    rpg = gregions // world                                                  # regions per GPU
+    owner_bounds = np.asarray(g.region_bounds[::rpg], dtype=np.int64)        # contiguous region blocks
+    nodes = int(owner_bounds[rank + 1] - owner_bounds[rank])                 # this rank's node count from here on
     C = R.nn.HIDDEN
     torch.manual_seed(42)                     # same random-init weights on every rank (run.py:71)
     model = R.RegionalTemporalGCN(node_features=F, num_nodes=nodes, periods=T, output_dim=O, num_regions=gregions)
@@ -151,8 +164,7 @@ def main():
                                 [t.to(dev) for t in g.region_attr], nodes)
         shard = None
     else:
-        owner_bounds = np.arange(world + 1, dtype=np.int64) * nodes
-        region_owner = [r // regions for r in range(gregions)]
+        region_owner = [r // rpg for r in range(gregions)]
         shard = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, gnodes, owner_bounds, region_owner,
                                    rank, world, dev)
         graph = shard.graph
@@ -239,11 +251,11 @@ def main():
     if rank == 0:
         M = nodes * T
         out = {
-            "metric": "training steps/sec (graph-snapshots/sec)", "value": world * args.steps / dt, "unit": "snapshots/s",
+            "metric": "training steps/sec (graph-snapshots/sec)", "value": (world if weak else 1) * args.steps / dt, "unit": "snapshots/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synthetic regional graph, {nodes} nodes / {edges} edges / {regions} regions "
-                                   f"per GPU, F={F}, T={T}, O={O}, hidden=256; RegionalTemporalGCN forward+MSE+backward per "
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: synthetic regional graph, {WORKLOADS[args.workload][0]} nodes / {edges} edges / {regions} regions "
+                                   f"{'per GPU' if weak else 'in total, split by regions over the GPUs'}, F={F}, T={T}, O={O}, hidden=256; RegionalTemporalGCN forward+MSE+backward per "
                                    "snapshot, RMSprop step once per K steps (run.py semantics)",
                        "global_nodes": gnodes, "global_edges": gedges, "global_regions": gregions,
                        "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: halo-row all-to-all per step (one step ahead, side stream) + 1 grad all-reduce",
