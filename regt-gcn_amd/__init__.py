@@ -7,7 +7,7 @@ from . import _lib
 from ._lib import RegtError, load as load_library
 from .graph import PreparedGraph, prepare_graph
 from .functional import RegTGCNFunction, regt_gcn_forward, param_names
-from . import ops, data, dist, train, evaluate
+from . import ops, data, dist, etl, train, evaluate
 from .nn import A3TGCN, ConvStackedA3TGCN, ConvStackedTemporalGCN, RegionalA3TGCN, RegionalTemporalGCN, TemporalGCN, TGCN
 
 __all__ = ["RegtError", "load_library", "PreparedGraph", "prepare_graph", "RegTGCNFunction", "regt_gcn_forward",

@@ -110,7 +110,9 @@ def main(argv=None):
     ap.add_argument("--num_timesteps_in", default=8, type=int)
     ap.add_argument("--num_timesteps_out", default=4, type=int)
     ap.add_argument("--model", default="RegionalTemporalGCN", choices=["RegionalTemporalGCN", "TemporalGCN", "ConvStackedTemporalGCN"])
-    ap.add_argument("--fixture", required=True, help=".npz with node_data (N,F,steps), edge_index, edge_attr, edge_<R>_index/attr")
+    ap.add_argument("--fixture", help=".npz with node_data (N,F,steps), edge_index, edge_attr, edge_<R>_index/attr")
+    ap.add_argument("--dataset_root", help="the reference's dataset/ directory (read through regtgcn_amd.etl)")
+    ap.add_argument("--max_steps", type=int, default=None, help="with --dataset_root: use the first MAX_STEPS timesteps")
     ap.add_argument("--out_dir", default="pretrained")
     ap.add_argument("--is_pretrained", action="store_true")
     ap.add_argument("--pretrained_model", default="")
@@ -118,7 +120,13 @@ def main(argv=None):
     a = ap.parse_args(argv)
     torch.manual_seed(a.seed)
     dev = torch.device("cuda:0")
-    d = np.load(a.fixture)
+    if a.dataset_root:
+        from . import etl
+        d = {k: v.numpy() for k, v in etl.load_tpims(a.dataset_root, a.max_steps).as_dict().items()}
+    elif a.fixture:
+        d = np.load(a.fixture)
+    else:
+        raise SystemExit("give --fixture or --dataset_root")
     node_data = torch.from_numpy(d["node_data"])
     n, f = node_data.shape[:2]
     xs, ys = snapshot_windows(node_data, a.num_timesteps_in, a.num_timesteps_out)
