@@ -67,6 +67,7 @@ def parse():
                          "the driver measures); strong = the ONE workload graph split by regions across the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3-split measurement")
+    ap.add_argument("--no-tpims-leg", action="store_true", help="skip the secondary TPIMS-scale (configs[1]) measurement")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
@@ -95,6 +96,55 @@ def cpu_baseline(nodes, edges, regions, F, T, O, seed=42):
     return {"value": 1.0 / (dt * T), "unit": "snapshots/s", "cores": cores, "kind": "port",
             "sample": f"1 of {T} periods (T=1 forward+loss+backward, {dt:.2f} s) of the same {nodes}-node/{edges}-edge/"
                       f"{regions}-region graph; periods are independent, step time = {T} x period time"}
+
+
+def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):
+    """BASELINE.json configs[1]: the reference's own graph (TPIMS, 104 sites after its site filter, 5 regions, F = 8), T = 12,
+    horizon 1 -- the other configuration the metric names.  Same step semantics as the headline loop; this size is bound
+    by the latency of ~45 dependent small kernels, not by any roofline."""
+    import regtgcn_amd as R
+    z = np.load(os.path.join(ROOT, "tests", "golden", "tpims_fixture.npz"))
+    fx = {k: torch.from_numpy(z[k]) for k in z.files if z[k].ndim > 0}
+    regs = ("IA", "KS", "KY", "OH", "WI")
+    n, T, O = fx["node_data"].shape[0], 12, 1
+    torch.manual_seed(42)
+    model = R.RegionalTemporalGCN(8, n, T, O).to(dev)
+    graph = model.prepare_graph(fx["edge_index"].to(dev), [fx[f"edge_{r}_index"].to(dev) for r in regs],
+                                [fx[f"edge_{r}_attr"].to(dev) for r in regs])
+    xs, ys = R.data.snapshot_windows(fx["node_data"], T, O)
+    xs, ys = [x.to(dev) for x in xs], [y.to(dev) for y in ys]
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+    def run(k):
+        for i in range(k):
+            pred, _ = model.forward_prepared(xs[i % len(xs)], graph)
+            torch.mean((pred - ys[i % len(xs)]) ** 2).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        torch.cuda.synchronize()
+
+    run(warmup)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    cpu = None
+    if with_cpu:                                # the oracle (CPU restatement of the reference path) on the same snapshots
+        from oracle import model as M
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        ri, rw = [fx[f"edge_{r}_index"] for r in regs], [fx[f"edge_{r}_attr"] for r in regs]
+        xc, yc = [x.cpu() for x in xs[:4]], [y.cpu() for y in ys[:4]]
+        k_cpu = 12
+        for i in range(k_cpu + 2):
+            if i == 2:
+                t1 = time.perf_counter()
+            pr, _ = M.regional_temporal_gcn(p, xc[i % 4], fx["edge_index"], ri, rw)
+            torch.mean((pr - yc[i % 4]) ** 2).backward()
+        cpu = {"value": k_cpu / (time.perf_counter() - t1), "unit": "snapshots/s", "kind": "port", "cores": torch.get_num_threads(),
+               "sample": f"{k_cpu} forward+loss+backward steps of the oracle on the same snapshots"}
+    return {"value": steps / dt, "unit": "snapshots/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "cpu_baseline": cpu,
+            "workload": f"TPIMS fixture: {n} nodes / {fx['edge_index'].shape[1]} edges / 5 regions, F=8, T={T}, O={O} (BASELINE configs[1]); "
+                        "launch-latency-bound"}
 
 
 def stage_flops(stage, M, C, F):
@@ -225,6 +275,7 @@ def main():
         for line in buf.value.decode().splitlines():
             name, cnt, ms = line.split()
             stages[name] = (int(cnt), float(ms))
+    final_loss = float(loss.detach())
     # Secondary, opt-in arithmetic (never the headline): the same K steps with the flat GEMMs on the bf16 matrix pipe
     # through an exact 3-way bf16 split of both fp32 operands (gemm_split.h).  N = 1 only, after the timed region.
     split_dt = None
@@ -242,11 +293,14 @@ def main():
         split_dt = time.perf_counter() - t1
         lib.regt_set_gemm_mode(prev)
         del loss_s
+    tpims = None
+    if world == 1 and not args.no_tpims_leg:
+        loss = None                         # let the headline model's workspaces go back to the pool
+        tpims = tpims_leg(dev, with_cpu=not args.no_cpu_baseline)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    final_loss = float(loss.detach())
 
     if rank == 0:
         M = nodes * T
@@ -297,6 +351,8 @@ def main():
                 "note": "REGT_GEMM_MODE=bf16x3: gate/candidate/regional GEMMs, their data gradients and the wide weight gradients as "
                         "6 bf16 partial products of an exact 3-way bf16 split, fp32 accumulate; passes the same parity suite; "
                         "NOT the headline value"}
+        if tpims is not None:
+            out["tpims_configs1"] = tpims
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nodes, edges, regions, F, T, O)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -5,9 +5,9 @@ import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(f"value={d['value']:.2f} {d['unit']}  ms/step={d['ms_per_step']:.3f}  n_gpus={d['n_gpus']}")
-for k in ("roofline", "roofline_spmm", "mfma_all_gemms", "opt_in_bf16x3_split", "cpu_baseline"):
+for k in ("roofline", "roofline_spmm", "mfma_all_gemms", "opt_in_bf16x3_split", "tpims_configs1", "cpu_baseline"):
     if k in d:
-        print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("sample", "note")})
+        print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d[k].items() if a not in ("sample", "note", "workload")})
 if "stages" in d:
     tot = 0.0
     for k, v in sorted(d["stages"].items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["launches"]):
