@@ -127,6 +127,20 @@ def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):
     t0 = time.perf_counter()
     run(steps)
     dt = time.perf_counter() - t0
+    # the same steps through functional.FusedTrainStep (three C-ABI calls + one axpy per step, no autograd)
+    stepper = R.functional.FusedTrainStep(model, graph, 8, T)
+
+    def run_fused(k):
+        for i in range(k):
+            stepper(xs[i % len(xs)], ys[i % len(xs)])
+        opt.step()
+        stepper.zero_grad()
+        torch.cuda.synchronize()
+
+    run_fused(warmup)
+    t0 = time.perf_counter()
+    run_fused(steps)
+    dtf = time.perf_counter() - t0
     cpu = None
     if with_cpu:                                # the oracle (CPU restatement of the reference path) on the same snapshots
         from oracle import model as M
@@ -142,7 +156,9 @@ def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):
             torch.mean((pr - yc[i % 4]) ** 2).backward()
         cpu = {"value": k_cpu / (time.perf_counter() - t1), "unit": "snapshots/s", "kind": "port", "cores": torch.get_num_threads(),
                "sample": f"{k_cpu} forward+loss+backward steps of the oracle on the same snapshots"}
-    return {"value": steps / dt, "unit": "snapshots/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "cpu_baseline": cpu,
+    return {"value": steps / dt, "unit": "snapshots/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "fused_train_step": {"value": steps / dtf, "unit": "snapshots/s", "ms_per_step": 1e3 * dtf / steps},
+            "cpu_baseline": cpu,
             "workload": f"TPIMS fixture: {n} nodes / {fx['edge_index'].shape[1]} edges / 5 regions, F=8, T={T}, O={O} (BASELINE configs[1]); "
                         "launch-latency-bound"}
 

@@ -190,6 +190,76 @@ class RegTGCNFunction(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
 
 
+class FusedTrainStep:
+    """The per-snapshot body of run.py::train() (forward, ``mean((out - y)**2)``, backward with accumulating gradients,
+    run.py:178-191) as three C-ABI calls -- regt_forward, regt_mse_loss_grad, regt_backward -- plus ONE axpy, without
+    autograd.  Same kernels and arithmetic as :class:`RegTGCNFunction`; what goes away is the host work per step
+    (autograd graph, 22 gradient allocations, 22 AccumulateGrad launches, the loss ops).  Measured at TPIMS size:
+    0.60 -> 0.54 ms per step -- that regime is bound by the ~45 dependent small kernels themselves, not by the host.
+
+    The parameters' ``.grad`` become views of one flat accumulator, so any torch optimizer works; clear them with
+    :meth:`zero_grad` (or ``optimizer.zero_grad(set_to_none=False)``).  Build it after ``model.to(device)``."""
+
+    def __init__(self, model, graph: PreparedGraph, num_features: int, periods: int, slope: float = 0.01):
+        lib = _lib.load()
+        self.lib, self.graph, self.regional = lib, graph, bool(model.regional)
+        names = param_names(self.regional)
+        named = dict(model.named_parameters())
+        self.params = [named[n] for n in names]
+        for n_, p_ in zip(names, self.params):
+            if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
+                raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
+        dev = self.params[0].device
+        tens = dict(zip(names, self.params))
+        N, F, T = graph.num_nodes, num_features, periods
+        Cdim = tens["tgnn.conv.bias"].numel()
+        O, H1 = tens["linear2.weight"].shape[0], tens["linear1.weight"].shape[0]
+        self.dims = _lib.Dims(N, T, F, Cdim, graph.num_regions, O, H1, 1 if self.regional else 0, float(slope))
+        self.gs = _graph_struct(graph, T)
+        self.wsb = lib.regt_workspace_bytes(C.byref(self.dims), self.gs.n_chunks, self.gs.overlap)
+        if self.wsb == 0:
+            _lib.check(1, "regt_workspace_bytes")
+        self.ws = torch.empty(self.wsb, dtype=torch.uint8, device=dev)
+        total = sum(p_.numel() for p_ in self.params)
+        pad = [(-p_.numel()) % 4 for p_ in self.params]              # keep every view 16-byte aligned
+        self.acc = torch.zeros(total + sum(pad), dtype=torch.float32, device=dev)
+        self.step_grad = torch.empty_like(self.acc)
+        views, off = {}, 0
+        for n_, p_, extra in zip(names, self.params, pad):
+            p_.grad = self.acc[off:off + p_.numel()].view_as(p_)
+            views[n_] = self.step_grad[off:off + p_.numel()].view_as(p_)
+            off += p_.numel() + extra
+        self.ps = _fill(_lib.Params(), tens, self.regional)
+        self.gr = _fill(_lib.Grads(), views, self.regional)
+        self._keep = (tens, views)
+        self.pred = torch.empty(N, O, dtype=torch.float32, device=dev)
+        self.hidden = torch.empty(N, Cdim, dtype=torch.float32, device=dev)
+        self.dpred = torch.empty_like(self.pred)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.shape_x = (N, F, T)
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        """One training step on snapshot (x (N,F,T), y (N,O)); returns the loss as a 1-element device tensor that the
+        next call overwrites."""
+        lib, st = self.lib, _stream()
+        if tuple(x.shape) != self.shape_x or x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous():
+            raise ValueError(f"x must be a contiguous float32 CUDA tensor of shape {self.shape_x}")
+        if tuple(y.shape) != tuple(self.pred.shape) or y.dtype != torch.float32 or not y.is_contiguous():
+            raise ValueError(f"y must be a contiguous float32 tensor of shape {tuple(self.pred.shape)}")
+        _lib.check(lib.regt_forward(C.byref(self.dims), C.byref(self.gs), C.byref(self.ps), _lib.ptr(x), _lib.ptr(self.pred),
+                                    _lib.ptr(self.hidden), _lib.ptr(self.ws), self.wsb, st), "regt_forward")
+        cnt = self.pred.numel()
+        _lib.check(lib.regt_mse_loss_grad(_lib.ptr(self.pred), _lib.ptr(y), _lib.ptr(self.dpred), _lib.ptr(self.loss), cnt, cnt, st),
+                   "regt_mse_loss_grad")
+        _lib.check(lib.regt_backward(C.byref(self.dims), C.byref(self.gs), C.byref(self.ps), C.byref(self.gr), _lib.ptr(self.dpred),
+                                     None, _lib.ptr(self.hidden), None, _lib.ptr(self.ws), self.wsb, st), "regt_backward")
+        self.acc.add_(self.step_grad)
+        return self.loss
+
+    def zero_grad(self):
+        self.acc.zero_()
+
+
 # ---- models whose embedding stage is not the regional one: cell on a caller-supplied hidden input ---------------------
 
 PARAM_NAMES_CELL = (

@@ -28,10 +28,19 @@ from .dist import HaloPipeline, Shard, allreduce_gradients, allreduce_sum
 REGIONS = ("IA", "KS", "KY", "OH", "WI")
 
 
-def train_epoch(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], graph, optimizer) -> Tuple[torch.Tensor, List[torch.Tensor]]:
-    """One epoch of run.py::train() on device-resident snapshots; returns (last loss, all losses) as device scalars."""
+def train_epoch(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], graph, optimizer, stepper=None) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """One epoch of run.py::train() on device-resident snapshots; returns (last loss, all losses) as device scalars.
+    ``stepper`` (functional.FusedTrainStep): the same steps without autograd -- for graphs so small that the host work
+    per step is the bound."""
     model.train()
     losses = []
+    if stepper is not None:
+        for x, y in zip(xs, ys):
+            losses.append(stepper(x, y).clone())
+        allreduce_gradients(list(model.parameters()))
+        optimizer.step()
+        stepper.zero_grad()
+        return losses[-1][0], [l[0] for l in losses]
     for x, y in zip(xs, ys):
         out, _ = model.forward_prepared(x, graph)
         loss = torch.mean((out - y) ** 2)
@@ -114,6 +123,7 @@ def main(argv=None):
     ap.add_argument("--dataset_root", help="the reference's dataset/ directory (read through regtgcn_amd.etl)")
     ap.add_argument("--max_steps", type=int, default=None, help="with --dataset_root: use the first MAX_STEPS timesteps")
     ap.add_argument("--out_dir", default="pretrained")
+    ap.add_argument("--fused_step", action="store_true", help="train through functional.FusedTrainStep (no autograd; faster on small graphs)")
     ap.add_argument("--is_pretrained", action="store_true")
     ap.add_argument("--pretrained_model", default="")
     ap.add_argument("--pretrained_model_epoch", default="0")
@@ -148,8 +158,14 @@ def main(argv=None):
     opt = torch.optim.RMSprop(model.parameters(), lr=a.lr, weight_decay=a.decay)
     out_dir = os.path.join(a.out_dir, a.model)
     os.makedirs(out_dir, exist_ok=True)
+    stepper = None
+    if a.fused_step:
+        if a.model == "ConvStackedTemporalGCN":
+            raise SystemExit("--fused_step covers RegionalTemporalGCN / TemporalGCN")
+        from .functional import FusedTrainStep
+        stepper = FusedTrainStep(model, graph, f, a.num_timesteps_in)
     for epoch in range(a.epochs + 1):
-        last, _ = train_epoch(model, tx, ty, graph, opt)
+        last, _ = train_epoch(model, tx, ty, graph, opt, stepper)
         rmse, mse = evaluate(model, vx, vy, graph)
         print("Train Loss: {:.4f}, Test RMSE: {:.4f}, MAE: {:.4f}".format(float(last), rmse, mse))   # run.py:236 format
         if epoch % 10 == 0:

@@ -323,3 +323,47 @@ def test_other_hidden_widths_match_oracle(R, hidden, mode):
         if k in M.UNUSED_PARAMS:
             continue
         np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=TOL, rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("model_name", ["RegionalTemporalGCN", "TemporalGCN"])
+def test_fused_train_step_equals_autograd_path(R, tpims, model_name):
+    """functional.FusedTrainStep (forward + loss gradient + backward through the C ABI, no autograd) accumulates exactly
+    the gradients of the module path and reports the same losses."""
+    t_in, t_out, k = 6, 2, 3
+    n = tpims["node_data"].shape[0]
+    xs, ys = R.data.snapshot_windows(tpims["node_data"][:, :, :t_in + t_out + k - 1], t_in, t_out)
+    xs, ys = _cuda_list(xs), _cuda_list(ys)
+    ri, rw = region_lists(tpims)
+
+    def build():
+        if model_name == "RegionalTemporalGCN":
+            m = R.RegionalTemporalGCN(8, n, t_in, t_out)
+            m.load_state_dict(M.init_params(model_name, 8, t_in, t_out, num_nodes=n, seed=31))
+            m = m.cuda()
+            return m, m.prepare_graph(tpims["edge_index"].cuda(), _cuda_list(ri), _cuda_list(rw))
+        m = R.TemporalGCN(8, t_in, t_out)
+        m.load_state_dict(M.init_params(model_name, 8, t_in, t_out, seed=31))
+        m = m.cuda()
+        return m, m.prepare_graph(tpims["edge_index"].cuda(), tpims["edge_attr"].cuda(), n)
+
+    ref, g_ref = build()
+    losses_ref = []
+    for x, y in zip(xs, ys):
+        pred, _ = ref.forward_prepared(x, g_ref)
+        loss = torch.mean((pred - y) ** 2)
+        loss.backward()
+        losses_ref.append(float(loss.detach()))
+    fused, g_f = build()
+    stepper = R.functional.FusedTrainStep(fused, g_f, 8, t_in)
+    losses = [float(stepper(x, y)) for x, y in zip(xs, ys)]
+    np.testing.assert_allclose(losses, losses_ref, rtol=1e-6)
+    for (k_, a), (_, b) in zip(ref.named_parameters(), fused.named_parameters()):
+        if a.grad is None:
+            assert b.grad is None, k_
+            continue
+        assert torch.equal(a.grad, b.grad), k_                      # same kernels, same accumulation order
+    opt = torch.optim.RMSprop(fused.parameters(), lr=1e-3, weight_decay=1e-4)
+    opt.step()
+    stepper.zero_grad()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in fused.parameters() if p.grad is not None)
+    float(stepper(xs[0], ys[0]))                                    # parameters updated in place: the stepper keeps working
