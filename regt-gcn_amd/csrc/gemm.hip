@@ -1083,8 +1083,9 @@ __global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
     // field-wise copy of the selected task (scalar selects; no dynamically indexed kernarg struct in scratch)
     const SgTask& T = B.task[ti];
     const long per = (long)T.m * T.n, total = per * T.nbatch;
-    const int sub = threadIdx.x & 7;
-    const long idx = ((long)(blockIdx.x - B.block_start[ti]) * 256 + threadIdx.x) / 8;
+    const int sp = T.split;                    // uniform per workgroup: a task starts on a workgroup boundary
+    const int sub = sp == 8 ? (threadIdx.x & 7) : 0;
+    const long idx = ((long)(blockIdx.x - B.block_start[ti]) * 256 + threadIdx.x) / sp;
     const bool valid = idx < total;
     float s = 0.f;
     int b = 0, i = 0, j = 0;
@@ -1099,13 +1100,15 @@ __global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
             for (int bb = b0; bb < b1; ++bb) {
                 const float* A = q.A + (long)bb * q.sab + (long)i * q.sai;
                 const float* Bp = q.B + (long)bb * q.sbb + (long)j * q.sbj;
-                for (int k = sub; k < q.k; k += 8) s = fmaf(A[(long)k * q.sak], Bp[(long)k * q.sbk], s);
+                for (int k = sub; k < q.k; k += sp) s = fmaf(A[(long)k * q.sak], Bp[(long)k * q.sbk], s);
             }
         }
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
+    if (sp == 8) {
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+    }
     if (valid && sub == 0) {
         if (T.init) s += T.init[(long)i * T.init_si];
         T.C[(long)b * T.scb + (long)i * T.sci + (long)j * T.scj] = s;
@@ -1117,9 +1120,14 @@ int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
     int blocks = 0;
     for (int t = 0; t < b.ntask; ++t) {
         b.block_start[t] = blocks;
-        const long outputs = (long)b.task[t].m * b.task[t].n * b.task[t].nbatch;
+        SgTask& task = b.task[t];
+        const long outputs = (long)task.m * task.n * task.nbatch;
         REGT_CHECK_ARG(outputs > 0, "small_gemm_multi: empty task %d", t);
-        blocks += cdiv(outputs * 8, 256);
+        long ksum = 0;                           // multiply-adds per output element
+        for (int q = 0; q < task.nterm; ++q) ksum += (long)task.term[q].k * (task.term[q].sum_batch ? task.term[q].batch : 1);
+        // eight lanes per output (strided k + xor tree) only pay off for long sums; a K = F product is one lane's work
+        task.split = ksum > 32 ? 8 : 1;
+        blocks += cdiv(outputs * task.split, 256);
     }
     b.block_start[b.ntask] = blocks;
     hipLaunchKernelGGL(small_gemm_multi_kernel, dim3(blocks), dim3(256), 0, st, b);

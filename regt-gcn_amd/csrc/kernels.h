@@ -100,6 +100,7 @@ struct SgTask {
     const float* init; long init_si;   // optional init[i*init_si] added to every column (nullptr: 0)
     int nterm;
     SgTerm term[3];
+    int split;                   // lanes per output element (set by launch_small_gemm_multi: 1 for short sums, 8 for long ones)
 };
 constexpr int SG_MAX_TASKS = 10;
 struct SgBatch {
