@@ -362,12 +362,16 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         EpiBiasAct e{L.y1, H1, p.head1_b, ACT_RELU, 0.f};
         PROF("head_fwd", st);
         TRY(launch_gemm_bias_act(S, N, H1, e, st));
-        GemmSegs S2{};
-        S2.nseg = 1;
-        S2.seg[0] = make_seg(L.y1, H1, p.head2_w, nullptr, H1, INT_MAX, H1, true);
-        S2.row_div = 1;
-        EpiBiasAct e2{pred, O, p.head2_b, ACT_NONE, 0.f};
-        TRY(launch_gemm_bias_act(S2, N, O, e2, st));
+        if (head2_skinny_ok(H1, O, L.y1, p.head2_w)) {
+            TRY(launch_head2_fwd(L.y1, p.head2_w, p.head2_b, pred, N, H1, O, st));
+        } else {
+            GemmSegs S2{};
+            S2.nseg = 1;
+            S2.seg[0] = make_seg(L.y1, H1, p.head2_w, nullptr, H1, INT_MAX, H1, true);
+            S2.row_div = 1;
+            EpiBiasAct e2{pred, O, p.head2_b, ACT_NONE, 0.f};
+            TRY(launch_gemm_bias_act(S2, N, O, e2, st));
+        }
     }
     return REGT_OK;
 }
@@ -399,8 +403,26 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
     // ---- head ----------------------------------------------------------------------------------
-    TRY(wgrad_full("wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
-    {   // d1 = (dpred A2) * (y1 > 0)
+    const bool skinny = head2_skinny_ok(H1, O, L.y1, p.head2_w);
+    if (skinny) {
+        {
+            PROF("wgrad_head2", st);
+            TRY(launch_head2_wgrad(dpred, L.y1, L.slab, N, H1, O, L.kchunk_head, L.nchunks_head, 1, st));
+        }
+        {
+            PROF("wgrad_reduce", st);
+            WgradReduceArgs r{};
+            r.slab = L.slab; r.nchunks = L.nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
+            r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
+            r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
+            TRY(launch_wgrad_reduce(r, st));
+        }
+        PROF("head_bwd", st);
+        TRY(launch_head2_bwd(dpred, p.head2_w, L.y1, L.d1, N, H1, O, st));
+    } else {
+        TRY(wgrad_full("wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
+    }
+    if (!skinny) {   // d1 = (dpred A2) * (y1 > 0)
         GemmSegs S{};
         S.nseg = 1;
         S.seg[0] = make_seg(dpred, O, p.head2_w, nullptr, H1, INT_MAX, O, false);

@@ -162,6 +162,132 @@ int launch_transpose3(const float* s0, const float* s1, const float* s2, int cou
     return REGT_OK;
 }
 
+// ---- the last layer of the head for a short horizon (output_dim <= 4) -------------------------------------------------
+// linear2 is (H1 -> O) with O = 1..4 in every configuration of the reference (run.py --num_timesteps_out): as a tiled
+// MFMA GEMM it is a 128-wide tile with one live column (and its gradients a K = O contraction).  These three kernels
+// do the same arithmetic as plain row-wise fp32 work at the HBM rate: one pass over y1 (N x H1) each.
+constexpr int SK_MAXO = 4;
+
+// pred[n, o] = sum_k y1[n, k] W2[o, k] + b2[o]; 32 lanes per row (float4 each), two rows per wave
+__global__ __launch_bounds__(256) void head2_fwd_kernel(const float* __restrict__ y1, const float* __restrict__ W2,
+                                                        const float* __restrict__ b2, float* __restrict__ pred, int N, int H1, int O) {
+    const int sub = threadIdx.x & 31;
+    const long groups = (long)gridDim.x * 8;                      // eight 32-lane groups per workgroup, one row each
+    for (long n = (long)blockIdx.x * 8 + (threadIdx.x >> 5); n < N; n += groups) {
+        float s[SK_MAXO] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 4 * sub; k < H1; k += 128) {
+            const float4 v = *reinterpret_cast<const float4*>(y1 + n * H1 + k);
+#pragma unroll
+            for (int o = 0; o < SK_MAXO; ++o)
+                if (o < O) {
+                    const float4 w = *reinterpret_cast<const float4*>(W2 + (long)o * H1 + k);
+                    s[o] = fmaf(v.x, w.x, fmaf(v.y, w.y, fmaf(v.z, w.z, fmaf(v.w, w.w, s[o]))));
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < SK_MAXO; ++o)
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) s[o] += __shfl_xor(s[o], off, 32);     // inside the row's 32 lanes
+        if (sub < O) pred[n * O + sub] = (sub == 0 ? s[0] : sub == 1 ? s[1] : sub == 2 ? s[2] : s[3]) + b2[sub];
+    }
+}
+
+// d1[n, k] = (y1[n, k] > 0) * sum_o dpred[n, o] W2[o, k]
+__global__ __launch_bounds__(256) void head2_bwd_kernel(const float* __restrict__ dpred, const float* __restrict__ W2,
+                                                        const float* __restrict__ y1, float* __restrict__ d1, long N, int H1, int O) {
+    const int h4 = H1 / 4;
+    const long total = N * h4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / h4;
+        const int k = 4 * (int)(i - n * h4);
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < SK_MAXO; ++o)
+            if (o < O) {
+                const float g = dpred[n * O + o];
+                const float4 w = *reinterpret_cast<const float4*>(W2 + (long)o * H1 + k);
+                a.x = fmaf(g, w.x, a.x); a.y = fmaf(g, w.y, a.y); a.z = fmaf(g, w.z, a.z); a.w = fmaf(g, w.w, a.w);
+            }
+        const float4 m = *reinterpret_cast<const float4*>(y1 + n * H1 + k);
+        a.x = m.x > 0.f ? a.x : 0.f; a.y = m.y > 0.f ? a.y : 0.f; a.z = m.z > 0.f ? a.z : 0.f; a.w = m.w > 0.f ? a.w : 0.f;
+        *reinterpret_cast<float4*>(d1 + n * H1 + k) = a;
+    }
+}
+
+// slab[chunk] = (dW2 partial (O x H1), db2 partial (O)) over the chunk's rows: dW2[o, k] = sum_n dpred[n, o] y1[n, k].
+// Thread = (float4 of k, one of 8 row subsets); the subsets are combined in fixed order through LDS, the chunks by the
+// ordinary wgrad_reduce_kernel -- same slab layout as wgrad_kernel, deterministic.
+__global__ __launch_bounds__(256) void head2_wgrad_kernel(const float* __restrict__ dpred, const float* __restrict__ y1,
+                                                          float* __restrict__ slab, long N, int H1, int O, int kchunk, int colsum) {
+    __shared__ float4 red[8][32][SK_MAXO];
+    __shared__ float redb[8][32][SK_MAXO];
+    const int c4 = threadIdx.x & 31, rs = threadIdx.x >> 5;
+    const long r0 = (long)blockIdx.x * kchunk, r1 = r0 + kchunk < N ? r0 + kchunk : N;
+    const long stride = (long)O * H1 + (colsum ? O : 0);
+    float* out = slab + (long)blockIdx.x * stride;
+    for (int kb = 0; kb < H1; kb += 128) {
+        const int k = kb + 4 * c4;
+        float4 acc[SK_MAXO];
+        float accb[SK_MAXO];
+#pragma unroll
+        for (int o = 0; o < SK_MAXO; ++o) { acc[o] = make_float4(0.f, 0.f, 0.f, 0.f); accb[o] = 0.f; }
+        if (k < H1)
+            for (long n = r0 + rs; n < r1; n += 8) {
+                const float4 v = *reinterpret_cast<const float4*>(y1 + n * H1 + k);
+#pragma unroll
+                for (int o = 0; o < SK_MAXO; ++o)
+                    if (o < O) {
+                        const float g = dpred[n * O + o];
+                        acc[o].x = fmaf(g, v.x, acc[o].x); acc[o].y = fmaf(g, v.y, acc[o].y);
+                        acc[o].z = fmaf(g, v.z, acc[o].z); acc[o].w = fmaf(g, v.w, acc[o].w);
+                        accb[o] += g;
+                    }
+            }
+#pragma unroll
+        for (int o = 0; o < SK_MAXO; ++o) { red[rs][c4][o] = acc[o]; redb[rs][c4][o] = accb[o]; }
+        __syncthreads();
+        if (rs == 0 && k < H1) {
+#pragma unroll
+            for (int o = 0; o < SK_MAXO; ++o)
+                if (o < O) {
+                    float4 s = red[0][c4][o];
+                    for (int g = 1; g < 8; ++g) { const float4 t = red[g][c4][o]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+                    *reinterpret_cast<float4*>(out + (long)o * H1 + k) = s;
+                }
+        }
+        if (colsum && kb == 0 && threadIdx.x < O) {
+            float s = 0.f;
+            for (int g = 0; g < 8; ++g) s += redb[g][0][threadIdx.x];
+            out[(long)O * H1 + threadIdx.x] = s;
+        }
+        __syncthreads();
+    }
+}
+
+bool head2_skinny_ok(int H1, int O, const void* y1, const void* W2) {
+    return O >= 1 && O <= SK_MAXO && H1 % 4 == 0 && ((reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(W2)) & 15) == 0;
+}
+int launch_head2_fwd(const float* y1, const float* W2, const float* b2, float* pred, int N, int H1, int O, hipStream_t st) {
+    int blocks = cdiv(N, 8);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(head2_fwd_kernel, dim3(blocks), dim3(256), 0, st, y1, W2, b2, pred, N, H1, O);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+int launch_head2_bwd(const float* dpred, const float* W2, const float* y1, float* d1, int N, int H1, int O, hipStream_t st) {
+    int blocks = cdiv((long)N * (H1 / 4), 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(head2_bwd_kernel, dim3(blocks), dim3(256), 0, st, dpred, W2, y1, d1, (long)N, H1, O);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+int launch_head2_wgrad(const float* dpred, const float* y1, float* slab, int N, int H1, int O, int kchunk, int nchunks, int colsum,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(head2_wgrad_kernel, dim3(nchunks), dim3(256), 0, st, dpred, y1, slab, (long)N, H1, O, kchunk, colsum);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 // loss = scale * sum (pred - y)^2 ;  dpred = 2 * scale * (pred - y)     (scale = 1 / (N_global * O))
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* y, float* dpred, float* loss_out,
                                                        long n, float scale) {

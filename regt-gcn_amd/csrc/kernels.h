@@ -135,6 +135,12 @@ void set_gemm_mode(int mode);
 
 int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
                       hipStream_t st);   // dst[b] = src[b]^T, b < count <= 3
+// last head layer for output_dim <= 4 as row-wise fp32 kernels (cell.hip)
+bool head2_skinny_ok(int H1, int O, const void* y1, const void* W2);
+int launch_head2_fwd(const float* y1, const float* W2, const float* b2, float* pred, int N, int H1, int O, hipStream_t st);
+int launch_head2_bwd(const float* dpred, const float* W2, const float* y1, float* d1, int N, int H1, int O, hipStream_t st);
+int launch_head2_wgrad(const float* dpred, const float* y1, float* slab, int N, int H1, int O, int kchunk, int nchunks, int colsum,
+                       hipStream_t st);
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {
     const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;
