@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "gemm_fast.h"
 #include "gemm_split.h"
+#include "gemm_small.h"
 
 namespace regt {
 
@@ -188,6 +189,23 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
     core.for_each_vec(acc, epi);
 }
 
+// Small problems: 64 x 64 tiles (gemm_small.h) -- same operands, segments and epilogues, a quarter of the work per tile.
+template <class EpiF, bool BT, bool REGION>
+__global__ __launch_bounds__(256, 4) void gemm_flat_small_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + SM_B - 1) / SM_B;
+    const long m0 = (long)(blockIdx.x / tiles_n) * SM_B;
+    const int n0 = (blockIdx.x % tiles_n) * SM_B;
+    RowMap rm{m0, 1, (int)((M - m0) < SM_B ? (M - m0) : SM_B)};
+    SmallCore<BT, REGION> core(S, rm, n0, N, lds);
+    core.plan();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    core.run(acc, relu_a != 0);
+    core.for_each_vec(acc, epi);
+}
+
 // 0: fp32 MFMA (default).  1: exact 3-way bf16 split of both operands, six partial products on the bf16 matrix pipe
 // (gemm_split.h) for the GEMMs whose B operand is stored [N][K].
 static int g_gemm_mode = -1;
@@ -236,8 +254,18 @@ static int launch_fast_core(const GemmSegs& S, long M, int N, EpiF f, int relu, 
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
+// fewer 128 x 128 tiles than this: the chip is mostly idle and one tile's latency is the kernel's duration
+constexpr long SMALL_TILE_LIMIT = 128;
+
 template <class EpiF, bool BT, bool REGION>
 static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
+    if (gemm_mode() == 0 && (long)cdiv(M, GBM) * cdiv(N, GBN) < SMALL_TILE_LIMIT) {
+        const long tiles = (long)cdiv(M, SM_B) * cdiv(N, SM_B);
+        hipLaunchKernelGGL((gemm_flat_small_kernel<EpiF, BT, REGION>), dim3((unsigned)tiles), dim3(256), SM_LDS_BYTES, st, S, M, N, f,
+                           relu);
+        REGT_CHECK_LAUNCH();
+        return REGT_OK;
+    }
     if constexpr (BT) {
         if (gemm_mode() == 1) return launch_fast_core<EpiF, SplitCore<REGION>>(S, M, N, f, relu, st);
     }

@@ -1,0 +1,210 @@
+// 64 x 64 tile variant of the segmented fp32-MFMA GEMM for SMALL problems (the reference's own graph: TPIMS, 104 nodes,
+// M = N*T ~ 10^3 rows).  With 128 x 128 tiles such a GEMM is 10-40 workgroups on a 256-CU chip and its duration is the
+// latency of ONE tile (K/32 slabs x 64 MFMAs x 64 cycles per wave: 30-50 us at K = 256-512).  Quartering the tile gives
+// 4x the workgroups and a quarter of the MFMA chain per wave; nothing else changes: same segments, region masking,
+// iteration table, buffer-descriptor loads (FastCore's statics), LDS row padding and epilogue functors.
+//
+// 256 threads = 4 waves 2 x 2, each wave ONE v_mfma_f32_32x32x2_f32 tile.  No scheduling tricks: operands of problems
+// this small come from L2 and there are four co-resident workgroups per CU to cover each other.
+#pragma once
+#include "gemm_fast.h"
+
+namespace regt {
+
+constexpr int SM_B = 64;                              // tile edge
+constexpr int SM_KROW = SM_B + 4;                     // 68 floats: k-major B rows / epilogue image rows
+constexpr int SM_TILE = SM_B * G_LDS_ROW;             // 2304 floats (>= 32 * 68)
+constexpr int SM_STAGE = 2 * SM_TILE;                 // A tile + B tile
+constexpr int SM_LDS_BYTES = 2 * SM_STAGE * 4 + G_TABLE_BYTES;
+
+template <bool BT, bool REGION>
+struct SmallCore {
+    using F = FastCore<BT, REGION>;                   // statics only: make_srd, srd_load, SRD_OOB
+    const GemmSegs& S;
+    RowMap rm;
+    int n0, N;
+    float* lds;
+    ItDesc* table;
+    int nit;
+    int tid, lane, wr, wc;
+    int areg[2];                                      // region of the thread's two A staging rows (REGION only)
+
+    __device__ __forceinline__ SmallCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_)
+        : S(s), rm(r), n0(n0_), N(N_), lds(lds_) {
+        tid = threadIdx.x;
+        lane = tid & 63;
+        const int wid = tid >> 6;
+        wr = wid >> 1;
+        wc = wid & 1;
+        table = reinterpret_cast<ItDesc*>(lds + 2 * SM_STAGE);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rr = (tid + 256 * i) >> 3;
+            areg[i] = 0;
+            if (REGION && rr < rm.nvalid) areg[i] = S.node_region[rm.grow(rr) / S.row_div];
+        }
+    }
+
+    // iteration table: as FastCore::plan
+    __device__ __forceinline__ void plan() {
+        int rmin = 0, rmax = 0;
+        int* red = reinterpret_cast<int*>(lds);
+        if (REGION) {
+            if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
+            __syncthreads();
+            if (tid < SM_B && tid < rm.nvalid) {
+                const int reg = S.node_region[rm.grow(tid) / S.row_div];
+                atomicMin(&red[0], reg);
+                atomicMax(&red[1], reg);
+            }
+            __syncthreads();
+            rmin = red[0];
+            rmax = red[1];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int n = 0;
+            for (int s = 0; s < S.nseg; ++s) {
+                const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
+                const bool reg = REGION && (g.flags & SEG_REGION);
+                const bool rep = (g.flags & SEG_REPEAT) != 0;
+                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : (rep ? g.nrep - 1 : 0);
+                for (int r = r0; r <= r1; ++r)
+                    for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
+                        ItDesc d;
+                        const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
+                        d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
+                        d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
+                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
+                        table[n++] = d;
+                    }
+            }
+            red[2] = n;
+        }
+        __syncthreads();
+        nit = red[2];
+        __syncthreads();
+    }
+
+    struct Srds { __amdgpu_buffer_rsrc_t a, b; int lda, ldb, K, k0, region; };
+    __device__ __forceinline__ Srds make_srds(const ItDesc& d) const {
+        Srds r;
+        r.lda = __builtin_amdgcn_readfirstlane((int)d.lda);
+        r.ldb = __builtin_amdgcn_readfirstlane((int)d.ldb);
+        r.K = __builtin_amdgcn_readfirstlane(d.K);
+        r.k0 = __builtin_amdgcn_readfirstlane(d.k0);
+        r.region = __builtin_amdgcn_readfirstlane(d.region);
+        r.a = F::make_srd(d.A + rm.base * d.lda);
+        const int ns = __builtin_amdgcn_readfirstlane(d.nsplit);
+        if (BT) r.b = F::make_srd(n0 < ns ? d.B0 + (long)n0 * d.ldb : d.B1 + (long)(n0 - ns) * d.ldb);
+        else r.b = F::make_srd(d.B0 + n0);
+        return r;
+    }
+    __device__ __forceinline__ float4 load_a(const Srds& d, int i) const {
+        const int slot = tid + 256 * i;
+        const int k = d.k0 + 4 * (slot & 7);
+        bool ok = (slot >> 3) < rm.nvalid && k < d.K;
+        if (REGION) ok = ok && (d.region < 0 || areg[i] == d.region);
+        return F::srd_load(d.a, ok ? 4u * (unsigned)((slot >> 3) * (int)rm.mul * d.lda + k) : F::SRD_OOB);
+    }
+    __device__ __forceinline__ float4 load_b(const Srds& d, int i) const {
+        const int slot = tid + 256 * i;
+        if (BT) {
+            const int nl = slot >> 3, k = d.k0 + 4 * (slot & 7);
+            const bool ok = n0 + nl < N && k < d.K;
+            return F::srd_load(d.b, ok ? 4u * (unsigned)(nl * d.ldb + k) : F::SRD_OOB);
+        } else {
+            const int k = d.k0 + (slot >> 4), nl = 4 * (slot & 15);
+            const bool ok = k < d.K && n0 + nl < N;
+            return F::srd_load(d.b, ok ? 4u * (unsigned)(k * d.ldb + nl) : F::SRD_OOB);
+        }
+    }
+    __device__ __forceinline__ void store(float* st, int i, float4 a, float4 b, bool relu) const {
+        if (relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+        const int slot = tid + 256 * i;
+        *reinterpret_cast<float4*>(st + (slot >> 3) * G_LDS_ROW + 4 * (slot & 7)) = a;
+        float* lb = st + SM_TILE;
+        if (BT) *reinterpret_cast<float4*>(lb + (slot >> 3) * G_LDS_ROW + 4 * (slot & 7)) = b;
+        else *reinterpret_cast<float4*>(lb + (slot >> 4) * SM_KROW + 4 * (slot & 15)) = b;
+    }
+    __device__ __forceinline__ void mfma_slab(const float* st, f32x16& acc) const {
+        const int lr = lane & 31, lh = lane >> 5;
+        const float* lb = st + SM_TILE;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 a = *reinterpret_cast<const float4*>(st + (wr * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
+            float4 b;
+            if (BT) {
+                b = *reinterpret_cast<const float4*>(lb + (wc * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
+            } else {
+                const float* q = lb + (kg * 8 + lh * 4) * SM_KROW + wc * 32 + lr;
+                b = make_float4(q[0], q[SM_KROW], q[2 * SM_KROW], q[3 * SM_KROW]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    }
+
+    __device__ __forceinline__ void run(f32x16& acc, bool relu_a) const {
+        if (nit == 0) return;
+        float4 ra[2], rb[2];
+        {
+            const Srds d = make_srds(table[0]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { ra[i] = load_a(d, i); rb[i] = load_b(d, i); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) store(lds, i, ra[i], rb[i], relu_a);
+        }
+        __syncthreads();
+        for (int it = 0; it + 1 < nit; ++it) {
+            const float* st = lds + (it & 1) * SM_STAGE;
+            float* nx = lds + ((it + 1) & 1) * SM_STAGE;
+            const Srds d = make_srds(table[it + 1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { ra[i] = load_a(d, i); rb[i] = load_b(d, i); }
+            mfma_slab(st, acc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) store(nx, i, ra[i], rb[i], relu_a);
+            __syncthreads();
+        }
+        mfma_slab(lds + ((nit - 1) & 1) * SM_STAGE, acc);
+        __syncthreads();
+    }
+
+    // LDS-staged vector epilogue: 16 threads per 64-column row, 16 rows per pass, 4 passes
+    __device__ __forceinline__ void stage(const f32x16& acc) const {
+        const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            lds[(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * SM_KROW + wc * 32 + lr] = acc[reg];
+        __syncthreads();
+    }
+    __device__ __forceinline__ int erow(int i) const { return (tid >> 4) + 16 * i; }
+    __device__ __forceinline__ int ecol() const { return n0 + 4 * (tid & 15); }
+    __device__ __forceinline__ float4 eread(int i) const {
+        return *reinterpret_cast<const float4*>(lds + erow(i) * SM_KROW + 4 * (tid & 15));
+    }
+    template <class Fn>
+    __device__ __forceinline__ void for_each_vec(const f32x16& acc, const Fn& f) const {
+        stage(acc);
+        const int c = ecol();
+        if (c < N) {
+            typename Fn::Aux aux[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = erow(j);
+                if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = erow(j);
+                if (r < rm.nvalid) f.apply(rm.grow(r), c, eread(j), aux[j]);
+            }
+        }
+        __syncthreads();
+    }
+};
+
+}  // namespace regt
