@@ -381,21 +381,17 @@ __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
 template <class Core>
 __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = Core::BM, BN = Core::BN, KROW = Core::EKROW, TPR = Core::ETPR;
     const long C = a.C, M = (long)a.num_nodes * a.T;
-    const int tiles_n = (a.C + GBN - 1) / GBN;
+    const int tiles_n = (a.C + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const long m0 = (long)(bid / tiles_n) * GBM;
-    const int n0 = (bid % tiles_n) * GBN;
-    const RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    const long m0 = (long)(bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+    const RowMap rm{m0, 1, (int)((M - m0) < BM ? (M - m0) : BM)};
     Core core(a.S, rm, n0, a.C, lds);
     core.plan();
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    typename Core::Acc acc;
+    Core::zero(acc);
     core.run(acc, false);
     core.stage(acc);
     const int c = core.ecol();
@@ -403,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     if (c < a.C) {
         const float4 b = ld4(a.bias + c);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < Core::EROWS / 4; ++g) {
             float4 Z[4], hv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -429,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
                     o.y = pt * (Z[j].y * hv[j].y + (1.0f - Z[j].y) * ht.y);
                     o.z = pt * (Z[j].z * hv[j].z + (1.0f - Z[j].z) * ht.z);
                     o.w = pt * (Z[j].w * hv[j].w + (1.0f - Z[j].w) * ht.w);
-                    *reinterpret_cast<float4*>(lds + r * G_LDS_KROW + 4 * (threadIdx.x & 31)) = o;   // own element
+                    *reinterpret_cast<float4*>(lds + r * KROW + 4 * (threadIdx.x & (TPR - 1))) = o;   // own element
                 }
             }
         }
@@ -437,9 +433,9 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     __syncthreads();
     // segmented sum over each node's rows inside the tile
     const int node1 = (int)((m0 + rm.nvalid - 1) / a.T);
-    const int items = (node1 - node0 + 1) * 32;
+    const int items = (node1 - node0 + 1) * TPR;
     for (int it = threadIdx.x; it < items; it += 256) {
-        const int node = node0 + (it >> 5), c4 = it & 31;
+        const int node = node0 + it / TPR, c4 = it % TPR;
         const int cc = n0 + 4 * c4;
         if (cc >= a.C) continue;
         long lo = (long)node * a.T - m0, hi = lo + a.T - 1;
@@ -447,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
         if (hi > rm.nvalid - 1) hi = rm.nvalid - 1;
         float4 s4 = make_float4(0, 0, 0, 0);
         for (long r = lo; r <= hi; ++r) {
-            const float4 v = *reinterpret_cast<const float4*>(lds + r * G_LDS_KROW + 4 * c4);
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * KROW + 4 * c4);
             s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         }
         float* o = a.OH + (long)node * C + cc;
@@ -470,6 +466,9 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
         if (gemm_mode() == 1)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        else if (ftiles < SMALL_TILE_LIMIT)      // small graph: 64 x 64 tiles (a node's T <= 64 rows still span at most two)
+            hipLaunchKernelGGL((gemm_cand_flat_kernel<SmallCore<true, false>>), dim3((unsigned)(cdiv(M, SM_B) * cdiv(a.C, SM_B))),
+                               dim3(256), SM_LDS_BYTES, st, a);
         else
             hipLaunchKernelGGL((gemm_cand_flat_kernel<FastCore<true, false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {

@@ -29,6 +29,17 @@ constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
 
 template <bool BT, bool REGION>
 struct FastCore {
+    // tile geometry seen by kernels with their own epilogue (candidate kernel)
+    static constexpr int BM = GBM, BN = GBN, EROWS = 16, ETPR = 32, EKROW = G_LDS_KROW;
+    typedef f32x16 Acc[2][2];
+    __device__ __forceinline__ static void zero(Acc& acc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
     const GemmSegs& S;
     RowMap rm;
     int n0, N;

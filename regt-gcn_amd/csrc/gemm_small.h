@@ -20,6 +20,12 @@ constexpr int SM_LDS_BYTES = 2 * SM_STAGE * 4 + G_TABLE_BYTES;
 template <bool BT, bool REGION>
 struct SmallCore {
     using F = FastCore<BT, REGION>;                   // statics only: make_srd, srd_load, SRD_OOB
+    static constexpr int BM = SM_B, BN = SM_B, EROWS = 4, ETPR = 16, EKROW = SM_KROW;
+    typedef f32x16 Acc;
+    __device__ __forceinline__ static void zero(Acc& acc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    }
     const GemmSegs& S;
     RowMap rm;
     int n0, N;
