@@ -155,6 +155,7 @@ struct Layout {
     float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r), bf16x3 split mode only
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
     int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
+    long slab_floats;
     size_t bytes;
 };
 
@@ -206,12 +207,14 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.cb_npb = (L.cb_npb + 3) / 4 * 4;
     L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
     L.dp_partial = take((long)L.cb_blocks * T);
-    long slab = (long)L.nchunks * (2 * C * C + 2 * C);
-    if ((long)L.nchunks_s * (2 * C * F + 2 * C) > slab) slab = (long)L.nchunks_s * (2 * C * F + 2 * C);
-    long s2 = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
-    long s3 = (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O);
-    if (s2 > slab) slab = s2;
-    if (s3 > slab) slab = s3;
+    // one slab region per weight gradient (their reductions are deferred into one launch, ReduceQueue): the sum of
+    // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
+    long slab = (long)L.nchunks * (C * C + C) + (long)L.nchunks * (2 * C * C + 2 * C)
+              + (long)L.nchunks_s * (C * F) + (long)L.nchunks_s * (2 * C * F) + (long)L.nchunks_s * (C * F + C)
+              + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64;
+    const long ar_uniform = (long)L.nchunks_s * C * F, ar_tab = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
+    slab += ar_tab > ar_uniform ? ar_tab : ar_uniform;
+    L.slab_floats = slab;
     L.slab = take(slab);
     L.dA0 = take(C * F);
     L.dAall = take(R * C * F);
@@ -377,19 +380,56 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
 }
 
 // out[Nout x Nin] (+ column sums) = P^T Q over uniform chunks, reduced deterministically.
-int wgrad_full(const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu, long M,
-               int kchunk, int nchunks, float* slab, float* out, long ldo, float* colsum, hipStream_t st) {
-    WgradArgs a{P, ldp, Nout, Q, ldq, Nin, q_relu, M, kchunk, nullptr, nchunks, slab, colsum ? 1 : 0};
+// Weight-gradient slabs and their reductions inside one backward pass: every wgrad gets its own slab region and its
+// reduction is only recorded; flush() runs all recorded reductions in ONE launch.  A region request that does not fit
+// flushes first and starts over at the base of the slab (stream order keeps that safe).
+struct ReduceQueue {
+    float* base;
+    long capacity, used = 0;
+    hipStream_t st;
+    WgradReduceBatch batch{};
+    ReduceQueue(float* b, long cap, hipStream_t s) : base(b), capacity(cap), st(s) {}
+    int take(long floats, float** out) {
+        floats = (floats + 63) & ~63L;
+        REGT_CHECK_ARG(floats <= capacity, "backward: weight-gradient slab of %ld floats exceeds the workspace region (%ld)", floats, capacity);
+        if (used + floats > capacity) TRY(flush());
+        *out = base + used;
+        used += floats;
+        return REGT_OK;
+    }
+    int push(const WgradReduceArgs& r) {
+        if (batch.n == WR_MAX_TASKS) TRY(flush_keep_slab());
+        batch.t[batch.n++] = r;
+        return REGT_OK;
+    }
+    int flush_keep_slab() {
+        if (batch.n) {
+            PROF("wgrad_reduce", st);
+            TRY(launch_wgrad_reduce_multi(batch, st));
+        }
+        batch.n = 0;
+        return REGT_OK;
+    }
+    int flush() {
+        TRY(flush_keep_slab());
+        used = 0;
+        return REGT_OK;
+    }
+};
+
+int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu,
+               long M, int kchunk, int nchunks, float* out, long ldo, float* colsum, hipStream_t st) {
+    WgradArgs a{P, ldp, Nout, Q, ldq, Nin, q_relu, M, kchunk, nullptr, nchunks, nullptr, colsum ? 1 : 0};
+    TRY(q.take((long)nchunks * wgrad_slab_stride(a), &a.slab));
     {
         PROF(name, st);
         TRY(launch_wgrad(a, st));
     }
-    PROF("wgrad_reduce", st);
     WgradReduceArgs r{};
-    r.slab = slab; r.nchunks = nchunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+    r.slab = a.slab; r.nchunks = nchunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
     r.Nout = Nout; r.Nin = Nin; r.chunk_group = nullptr; r.ngroups = 1; r.out = out; r.ldo = ldo; r.group_stride = 0;
     r.colsum_out = colsum; r.colsum_offset = (long)Nout * Nin; r.ncolsum = Nout; r.accumulate = 0;
-    return launch_wgrad_reduce(r, st);
+    return q.push(r);
 }
 
 // `h_ext` / `dh_ext` != NULL (regt_cell_backward): the hidden input was supplied by the caller; its gradient is
@@ -403,24 +443,24 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
     // ---- head ----------------------------------------------------------------------------------
+    ReduceQueue rq(L.slab, L.slab_floats, st);
     const bool skinny = head2_skinny_ok(H1, O, L.y1, p.head2_w);
     if (skinny) {
+        float* slab = nullptr;
+        TRY(rq.take((long)L.nchunks_head * ((long)O * H1 + O), &slab));
         {
             PROF("wgrad_head2", st);
-            TRY(launch_head2_wgrad(dpred, L.y1, L.slab, N, H1, O, L.kchunk_head, L.nchunks_head, 1, st));
+            TRY(launch_head2_wgrad(dpred, L.y1, slab, N, H1, O, L.kchunk_head, L.nchunks_head, 1, st));
         }
-        {
-            PROF("wgrad_reduce", st);
-            WgradReduceArgs r{};
-            r.slab = L.slab; r.nchunks = L.nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
-            r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
-            r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
-            TRY(launch_wgrad_reduce(r, st));
-        }
+        WgradReduceArgs r{};
+        r.slab = slab; r.nchunks = L.nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
+        r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
+        r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
+        TRY(rq.push(r));
         PROF("head_bwd", st);
         TRY(launch_head2_bwd(dpred, p.head2_w, L.y1, L.d1, N, H1, O, st));
     } else {
-        TRY(wgrad_full("wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head2_w, H1, gr.head2_b, st));
+        TRY(wgrad_full(rq, "wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, gr.head2_w, H1, gr.head2_b, st));
     }
     if (!skinny) {   // d1 = (dpred A2) * (y1 > 0)
         GemmSegs S{};
@@ -431,7 +471,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         PROF("head_bwd", st);
         TRY(launch_gemm_mask_add(S, N, H1, e, st));
     }
-    TRY(wgrad_full("wgrad_head1", L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, L.slab, gr.head1_w, C, gr.head1_b, st));
+    TRY(wgrad_full(rq, "wgrad_head1", L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, gr.head1_w, C, gr.head1_b, st));
     {   // dOH = (d1 A1) * (hidden > 0) + dhidden
         GemmSegs S{};
         S.nseg = 1;
@@ -480,51 +520,52 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
-    TRY(wgrad_full("wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, L.slab, gr.gate_w[2] + C, 2L * C, L.dch, st));
-    TRY(wgrad_full("wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, L.dGh, F, nullptr, st));
+    TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st));
+    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
-        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, L.slab, 1};
+        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Uzr", st);
             TRY(launch_wgrad(a, st));
         }
-        PROF("wgrad_reduce", st);
         for (int k = 0; k < 2; ++k) {
             WgradReduceArgs r{};
-            r.slab = L.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a);
+            r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a);
             r.elem_offset = (long)k * C * C; r.Nout = C; r.Nin = C; r.ngroups = 1;
             r.out = gr.gate_w[k] + C; r.ldo = 2L * C;
             r.colsum_out = k == 0 ? L.dczr : nullptr; r.colsum_offset = 2L * C * C; r.ncolsum = 2 * C;
-            TRY(launch_wgrad_reduce(r, st));
+            TRY(rq.push(r));
         }
     }
-    TRY(wgrad_full("wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, L.dGzr, F, nullptr, st));
+    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
-    if (!h_ext) TRY(wgrad_full("wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dA0, F, dbpr, st));
+    if (!h_ext) TRY(wgrad_full(rq, "wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, dA0, F, dbpr, st));
     if (h_ext) {
         // no embedding stage behind a caller-supplied hidden input
     } else if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
         for (int r = 0; r < R; ++r)
-            TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab,
+            TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s,
                            dAall + (long)r * C * F, F, nullptr, st));
     } else if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
-        WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, L.slab, 0};
+        WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, nullptr, 0};
+        TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Ar", st);
             TRY(launch_wgrad(a, st));
         }
-        PROF("wgrad_reduce", st);
         WgradReduceArgs r{};
-        r.slab = L.slab; r.nchunks = g.n_chunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+        r.slab = a.slab; r.nchunks = g.n_chunks; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
         r.Nout = C; r.Nin = F; r.chunk_group = g.chunk_region; r.ngroups = R; r.out = dAall; r.ldo = F;
         r.group_stride = (long)C * F;
-        TRY(launch_wgrad_reduce(r, st));
+        TRY(rq.push(r));
     } else {
-        TRY(wgrad_full("wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.slab, dAall, F, nullptr, st));
+        TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, dAall, F, nullptr, st));
     }
+    TRY(rq.flush());      // every slab reduction of this backward pass, one launch
     // ---- back through the weight compositions (tiny; two launches) ---------------------------------------
     PROF("compose_bwd", st);
     {
@@ -660,7 +701,10 @@ int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, 
     REGT_CHECK_ARG(dOut && A && dW && slab && M > 0 && N > 0 && K > 0, "regt_wgrad: bad argument");
     int kc, nc;
     wgrad_chunks(M, &kc, &nc);
-    return wgrad_full("wgrad", dOut, ldd, N, A, lda, K, 0, M, kc, nc, slab, dW, ldw, dbias, (hipStream_t)st);
+    // the caller's slab is sized by regt_wgrad_slab_floats; the 64-float alignment slack of the queue is not needed here
+    ReduceQueue rq(slab, ((long)nc * ((long)N * K + (dbias ? N : 0)) + 63) & ~63L, (hipStream_t)st);
+    TRY(wgrad_full(rq, "wgrad", dOut, ldd, N, A, lda, K, 0, M, kc, nc, dW, ldw, dbias, (hipStream_t)st));
+    return rq.flush();
 }
 
 size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks, int32_t overlap) {

@@ -1001,13 +1001,13 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 // Eight adjacent lanes share one output element: the chunk range is strided over them and combined with
 // a fixed xor-shuffle tree, so the order of the additions is fixed (deterministic) and small outputs
 // (the C x F gradients) still fill the chip.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
+__device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long block, long nblocks) {
     const long per = (long)a.Nout * a.Nin;
     const long total = per * a.ngroups;
     const long ncs = a.colsum_out ? a.ncolsum : 0;
     const int sub = threadIdx.x & 7;
-    const long stride = (long)gridDim.x * blockDim.x / 8;
-    long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) / 8;
+    const long stride = nblocks * 256 / 8;
+    long idx = (block * 256 + threadIdx.x) / 8;
     long wfirst = idx - (threadIdx.x % 64) / 8;
     for (; wfirst < total + ncs; wfirst += stride, idx += stride) {
         const bool valid = idx < total + ncs;
@@ -1038,6 +1038,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradReduceArgs a) { wgrad_reduce_body(a, blockIdx.x, gridDim.x); }
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceBatch B) {
+    int ti = 0;
+    while (ti + 1 < B.n && (int)blockIdx.x >= B.block_start[ti + 1]) ++ti;
+    wgrad_reduce_body(B.t[ti], (long)blockIdx.x - B.block_start[ti], (long)B.block_start[ti + 1] - B.block_start[ti]);
+}
+
+static int wgrad_reduce_blocks(const WgradReduceArgs& a) {
+    long total = ((long)a.Nout * a.Nin * a.ngroups + (a.colsum_out ? a.ncolsum : 0)) * 8;
+    int blocks = cdiv(total, 256);
+    return blocks > 16384 ? 16384 : blocks;
+}
+
+int launch_wgrad_reduce_multi(WgradReduceBatch& b, hipStream_t st) {
+    REGT_CHECK_ARG(b.n > 0 && b.n <= WR_MAX_TASKS, "wgrad_reduce_multi: %d tasks", b.n);
+    int blocks = 0;
+    for (int t = 0; t < b.n; ++t) {
+        REGT_CHECK_ARG(!(b.t[t].colsum_out && b.t[t].ngroups != 1), "wgrad_reduce: colsum only with one group");
+        b.block_start[t] = blocks;
+        blocks += wgrad_reduce_blocks(b.t[t]);
+    }
+    b.block_start[b.n] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, st, b);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
 }
 
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st) {

@@ -74,6 +74,14 @@ struct WgradReduceArgs {
     int accumulate;           // add into out instead of overwrite
 };
 int launch_wgrad_reduce(const WgradReduceArgs& a, hipStream_t st);
+// several independent reductions in one launch (the backward pass defers all of its slab reductions to one place)
+constexpr int WR_MAX_TASKS = 12;
+struct WgradReduceBatch {
+    int n;
+    int block_start[WR_MAX_TASKS + 1];
+    WgradReduceArgs t[WR_MAX_TASKS];
+};
+int launch_wgrad_reduce_multi(WgradReduceBatch& b, hipStream_t st);
 
 // ---- tiny strided batched GEMM (weight composition and its backward) ---------------------------
 //   C[b][i, j] (+)= sum_over_batch? sum_k A[b][i, k] * B[b][k, j]      arbitrary strides
