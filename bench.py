@@ -168,7 +168,7 @@ def stage_flops(stage, M, C, F):
         "gemm_gates": 2.0 * M * 2 * C * (C + F), "gemm_candidate": 2.0 * M * C * (C + F),
         "gemm_regional": 2.0 * M * C * 2 * F, "dgrad_candidate": 2.0 * M * C * C, "dgrad_gates": 2.0 * M * C * 2 * C,
         "wgrad_Uh": 2.0 * M * C * C, "wgrad_Uzr": 2.0 * M * 2 * C * C, "wgrad_Gh": 2.0 * M * C * F,
-        "wgrad_Gzr": 2.0 * M * 2 * C * F, "wgrad_A0": 2.0 * M * C * F, "wgrad_Ar": 2.0 * M * C * F,
+        "wgrad_Gzr": 2.0 * M * 2 * C * F, "wgrad_A0": 2.0 * M * C * F, "wgrad_Ar": 2.0 * M * C * F, "wgrad_A0_Ar": 2.0 * M * C * 2 * F,
     }.get(stage)
 
 

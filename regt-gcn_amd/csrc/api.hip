@@ -214,6 +214,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
               + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64;
     const long ar_uniform = (long)L.nchunks_s * C * F, ar_tab = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
     slab += ar_tab > ar_uniform ? ar_tab : ar_uniform;
+    slab += (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * (C * F + C);     // fused dA0 | dA_r slabs over the region chunk table
     L.slab_floats = slab;
     L.slab = take(slab);
     L.dA0 = take(C * F);
@@ -542,9 +543,32 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
-    if (!h_ext) TRY(wgrad_full(rq, "wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, dA0, F, dbpr, st));
-    if (h_ext) {
-        // no embedding stage behind a caller-supplied hidden input
+    // node-disjoint regions (the headline case): dA0 = ds^T x and dA_r = ds^T (L~ x) share ds -- one launch over the
+    // region-pure row chunks with [x | L~ x] as a two-part right-hand side, so that ds is read from HBM once
+    const bool fuse_a = !h_ext && !g.overlap && R > 1 && F % 32 == 0;
+    if (fuse_a) {
+        REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
+        WgradArgs a{L.dh, C, C, Xp, F, 2 * F, 0, M, 0, g.chunk_tab, g.n_chunks, nullptr, 1};
+        a.Q2 = L.LX; a.ldq2 = F; a.nin_split = F;
+        TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
+        {
+            PROF("wgrad_A0_Ar", st);
+            TRY(launch_wgrad(a, st));
+        }
+        WgradReduceArgs r0{};
+        r0.slab = a.slab; r0.nchunks = g.n_chunks; r0.slab_stride = wgrad_slab_stride(a); r0.elem_offset = 0; r0.slab_ld = 2 * F;
+        r0.Nout = C; r0.Nin = F; r0.chunk_group = nullptr; r0.ngroups = 1; r0.out = dA0; r0.ldo = F;
+        r0.colsum_out = dbpr; r0.colsum_offset = 2L * C * F; r0.ncolsum = C;
+        TRY(rq.push(r0));
+        WgradReduceArgs r1{};
+        r1.slab = a.slab; r1.nchunks = g.n_chunks; r1.slab_stride = wgrad_slab_stride(a); r1.elem_offset = F; r1.slab_ld = 2 * F;
+        r1.Nout = C; r1.Nin = F; r1.chunk_group = g.chunk_region; r1.ngroups = R; r1.out = dAall; r1.ldo = F;
+        r1.group_stride = (long)C * F;
+        TRY(rq.push(r1));
+    }
+    if (!h_ext && !fuse_a) TRY(wgrad_full(rq, "wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, dA0, F, dbpr, st));
+    if (h_ext || fuse_a) {
+        // no embedding stage behind a caller-supplied hidden input / already done above
     } else if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
         for (int r = 0; r < R; ++r)
             TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s,

@@ -533,8 +533,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     // Both operands stream through wave-uniform buffer descriptors based at the chunk's first row
     // (vector path: ldp/ldq multiples of 4 and 16-B aligned bases, checked on the host).
     const __amdgpu_buffer_rsrc_t sp = Core::make_srd(a.P + r0 * a.ldp + i0);
-    const __amdgpu_buffer_rsrc_t sq = Core::make_srd(a.Q + r0 * a.ldq + j0);
-    const int ldp = (int)a.ldp, ldq = (int)a.ldq;
+    const bool second = a.Q2 != nullptr && j0 >= a.nin_split;          // this column tile reads the second operand
+    const __amdgpu_buffer_rsrc_t sq = second ? Core::make_srd(a.Q2 + r0 * a.ldq2 + (j0 - a.nin_split)) : Core::make_srd(a.Q + r0 * a.ldq + j0);
+    const int ldp = (int)a.ldp, ldq = second ? (int)a.ldq2 : (int)a.ldq;
 
     auto load = [&](int k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
 #pragma unroll
@@ -970,13 +971,15 @@ long wgrad_slab_stride(const WgradArgs& a) { return (long)a.Nout * a.Nin + (a.co
 
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.Nout > 0 && a.Nin > 0 && a.nchunks > 0, "wgrad: empty problem");
-    const bool wide = a.Nin > 32;
+    const bool wide = a.Nin > 32 && !a.Q2;
     const int bnw = wide ? 128 : 32;
     long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
     REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
     size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
     const bool fast = a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.Nout % 4 == 0 && a.Nin % 4 == 0 && a16(a.P) && a16(a.Q) &&
-                      a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536);
+                      a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536) &&
+                      (!a.Q2 || (a.ldq2 % 4 == 0 && a.ldq2 < (1L << 20) && a16(a.Q2) && a.nin_split % 32 == 0));
+    REGT_CHECK_ARG(!a.Q2 || fast, "wgrad: a second right-hand operand needs 16-byte tileable operands and nin_split %% 32 == 0");
     if (wide) {
         static bool attr_done = false, attr_done_g = false, attr_done_s = false;
         if (fast && gemm_mode() == 1) {
@@ -1018,8 +1021,9 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long
             if (idx < total) {
                 g = (int)(idx / per);
                 e = idx - (long)g * per;
+                const long se = a.slab_ld ? (e / a.Nin) * a.slab_ld + e % a.Nin : e;
                 for (int c = sub; c < a.nchunks; c += 8)
-                    if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + e];
+                    if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + se];
             } else {
                 for (int c = sub; c < a.nchunks; c += 8) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + (idx - total)];
             }

@@ -57,6 +57,9 @@ struct WgradArgs {
     int nchunks;
     float* slab;              // (nchunks, Nout*Nin + (colsum ? Nout : 0))
     int colsum;               // also produce column sums of P (bias gradient)
+    // optional second right-hand operand (skinny kernel only): output columns >= nin_split come from Q2 (column j -
+    // nin_split).  Two gradients that share P -- dA0 = ds^T x and dA_r = ds^T (L~ x) -- then read P from HBM once.
+    const float* Q2 = nullptr; long ldq2 = 0; int nin_split = 0;
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t st);
 long wgrad_slab_stride(const WgradArgs& a);
@@ -64,6 +67,7 @@ long wgrad_slab_stride(const WgradArgs& a);
 struct WgradReduceArgs {
     const float* slab; int nchunks; long slab_stride;
     long elem_offset;         // first slab element of the (Nout x Nin) block to reduce
+    long slab_ld;             // row stride of that block inside a slab (0: dense, = Nin)
     int Nout, Nin;
     const int* chunk_group;   // optional (nchunks): output group of each chunk
     int ngroups;
