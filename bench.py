@@ -53,6 +53,7 @@ WORKLOADS = {
     # name: (nodes, edges, regions, F, T, O) per GPU
     "cfg3": (100_000, 1_000_000, 8, 32, 12, 1),
     "small": (20_000, 200_000, 8, 32, 12, 1),       # quick functional run
+    "cfg3r64": (100_000, 1_000_000, 64, 32, 12, 1), # cfg-3 with the region count of the 8-GPU global graph (compose cost check)
 }
 
 

@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 2
+#define REGT_ABI_VERSION 3
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -129,6 +129,11 @@ typedef struct regt_graph {
      * load_dataset.py:324-329).  rowptr/col/val then hold (1+R)*N rows: A_hat, then one scaled Laplacian per
      * region; node_region / chunk tables / merged operator are ignored. */
     int32_t overlap;
+    /* Region ids [region_lo, region_hi) that own rows of THIS graph (a region shard of a multi-GPU run owns a block of
+     * the global regions; tgnn.linear stays replicated at its global size).  Per-region composed weights are only
+     * built for these, and the gradient blocks of the other regions receive just the term every region shares.
+     * 0, 0 = all of [0, R). */
+    int32_t region_lo, region_hi;
 } regt_graph;
 
 typedef struct regt_params {

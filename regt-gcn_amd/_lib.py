@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libregtgcn_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -30,7 +30,8 @@ class Dims(C.Structure):
 class Graph(C.Structure):
     _fields_ = [("rowptr", vp), ("col", vp), ("val", vp), ("node_region", vp), ("chunk_tab", vp),
                 ("chunk_region", vp), ("n_chunks", C.c_int32),
-                ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp), ("overlap", C.c_int32)]
+                ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp), ("overlap", C.c_int32),
+                ("region_lo", C.c_int32), ("region_hi", C.c_int32)]
 
 
 _PARAM_FIELDS = [("attention", vp), ("conv_lin_w", vp * 3), ("conv_bias", vp * 3), ("gate_w", vp * 3),

@@ -150,6 +150,8 @@ struct Layout {
     // saved by forward
     float *Xp, *AX, *LX, *h, *ZR, *q, *Ht, *y1, *probs;
     float *A0, *Aall, *bprime, *Gzr, *Gh, *czr, *ch;
+    float *S;    // (C, C): sum of the region blocks of tgnn.linear.weight (forward, reused by backward)
+    float *G0;   // (C, C): the part of d tgnn.linear.weight every region block shares (backward)
     // backward temporaries
     float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
     float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r), bf16x3 split mode only
@@ -178,6 +180,8 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.Ht = take(M * C);
     L.y1 = take(N * H1);
     L.probs = take(T);
+    L.S = take(C * C);
+    L.G0 = take(C * C);
     L.A0 = take(C * F);
     L.Aall = take(R * C * F);
     L.bprime = take(C);
@@ -257,23 +261,34 @@ SgTerm term(const float* A, long sai, long sak, long sab, const float* B, long s
     return SgTerm{A, sai, sak, sab, B, sbk, sbj, sbb, k, batch, sum_batch};
 }
 void add_task(SgBatch& b, float* C, long sci, long scj, long scb, int m, int n, int nbatch, const float* init, long init_si,
-              std::initializer_list<SgTerm> terms) {
+              std::initializer_list<SgTerm> terms, long init_sj = 0) {
     SgTask& t = b.task[b.ntask++];
     t = SgTask{};
     t.C = C; t.sci = sci; t.scj = scj; t.scb = scb; t.m = m; t.n = n; t.nbatch = nbatch; t.init = init; t.init_si = init_si;
+    t.init_sj = init_sj;
     for (const SgTerm& q : terms) t.term[t.nterm++] = q;
 }
 
 // All weight compositions of one step in ONE launch (SURVEY/DESIGN section 3, item 2).
-int compose_forward(const regt_dims& d, const regt_params& p, const Layout& L, hipStream_t st) {
+// owned region block [lo, hi) of a graph (regt_graph.region_lo / region_hi; 0, 0 = all)
+void region_range(const regt_dims& d, const regt_graph& g, int* lo, int* hi) {
+    *lo = 0; *hi = d.R;
+    if (g.region_hi > g.region_lo && g.region_lo >= 0 && g.region_hi <= d.R) { *lo = g.region_lo; *hi = g.region_hi; }
+}
+
+int compose_forward(const regt_dims& d, const regt_graph& g, const regt_params& p, const Layout& L, hipStream_t st) {
     const int C = d.C, F = d.F, R = d.R;
     const long RC = (long)R * C;
     SgBatch b{};
     if (d.regional) {
-        // A0 = sum_r Wl_r W0 ;  A_r = Wl_r W1 ;  b' = sum_r Wl_r b_c + b_l
-        add_task(b, L.A0, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, RC, 1, C, p.cheb_w0, F, 1, 0, C, R, 1)});
-        add_task(b, L.Aall, F, 1, (long)C * F, C, F, R, nullptr, 0, {term(p.region_w, RC, 1, C, p.cheb_w1, F, 1, 0, C)});
-        add_task(b, L.bprime, 1, 0, 0, C, 1, 1, p.region_b, 1, {term(p.region_w, RC, 1, C, p.cheb_bias, 1, 0, 0, C, R, 1)});
+        int lo, hi;
+        region_range(d, g, &lo, &hi);
+        // S = sum_r Wl_r ;  A0 = S W0 ;  A_r = Wl_r W1 (owned regions only) ;  b' = S b_c + b_l
+        TRY(launch_sum_region_blocks(p.region_w, L.S, C, R, st));
+        add_task(b, L.A0, F, 1, 0, C, F, 1, nullptr, 0, {term(L.S, C, 1, 0, p.cheb_w0, F, 1, 0, C)});
+        add_task(b, L.Aall + (long)lo * C * F, F, 1, (long)C * F, C, F, hi - lo, nullptr, 0,
+                 {term(p.region_w + (long)lo * C, RC, 1, C, p.cheb_w1, F, 1, 0, C)});
+        add_task(b, L.bprime, 1, 0, 0, C, 1, 1, p.region_b, 1, {term(L.S, C, 1, 0, p.cheb_bias, 1, 0, 0, C)});
     }
     for (int k = 0; k < 3; ++k) {
         float* G = k < 2 ? L.Gzr + (long)k * C * F : L.Gh;
@@ -296,7 +311,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         PROF("compose_fwd", st);
         TRY(launch_softmax_small(p.attention, L.probs, T, st));
-        TRY(compose_forward(d, p, L, st));
+        TRY(compose_forward(d, g, p, L, st));
     }
     // 1. pack the snapshot and aggregate: [A_hat; L~] x  (one stacked SpMM over 2N rows, width T*F)
     const float* Xp = xp_ext ? xp_ext : L.Xp;
@@ -604,6 +619,9 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             add_task(b, gr.conv_lin_w[k], F, 1, 0, C, F, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dG, F, 1, 0, C)});
             add_task(b, gr.conv_bias[k], 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, C)});
         }
+        if (d.regional)      // G0 = dA0 W0^T + db' b_c^T: what EVERY block of d tgnn.linear.weight receives (A0 and b' sum over all regions)
+            add_task(b, L.G0, C, 1, 0, C, C, 1, nullptr, 0,
+                     {term(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, F), term(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, 1)});
         TRY(launch_small_gemm_multi(b, st));
     }
     {
@@ -612,14 +630,18 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             add_task(b, gr.gate_b[k], 1, 0, 0, C, 1, 1, k < 2 ? L.dczr + (long)k * C : L.dch, 1, {});
         if (d.regional) {
             const long RC = (long)R * C;
-            // dWl_r = dA_r W1^T + dA0 W0^T + db' b_c^T
-            add_task(b, gr.region_w, RC, 1, C, C, C, R, nullptr, 0,
-                     {term(L.dAall, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, F), term(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, F),
-                      term(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, 1)});
-            // dW0 = (sum_r Wl_r)^T dA0 ; dW1 = sum_r Wl_r^T dA_r ; db_c = (sum_r Wl_r)^T db' ; db_l = db'
-            add_task(b, gr.cheb_w0, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dA0, F, 1, 0, C, R, 1)});
-            add_task(b, gr.cheb_w1, F, 1, 0, C, F, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dAall, F, 1, (long)C * F, C, R, 1)});
-            add_task(b, gr.cheb_bias, 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.region_w, 1, RC, C, L.dbprime, 1, 0, 0, C, R, 1)});
+            int lo, hi;
+            region_range(d, g, &lo, &hi);
+            // dWl_r = G0 + dA_r W1^T for the owned regions, G0 alone for the others (their rows live on other GPUs)
+            add_task(b, gr.region_w + (long)lo * C, RC, 1, C, C, C, hi - lo, L.G0, C,
+                     {term(L.dAall + (long)lo * C * F, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, F)}, 1);
+            if (lo > 0) add_task(b, gr.region_w, RC, 1, C, C, C, lo, L.G0, C, {}, 1);
+            if (hi < R) add_task(b, gr.region_w + (long)hi * C, RC, 1, C, C, C, R - hi, L.G0, C, {}, 1);
+            // dW0 = S^T dA0 ; dW1 = sum_{owned r} Wl_r^T dA_r ; db_c = S^T db' ; db_l = db'
+            add_task(b, gr.cheb_w0, F, 1, 0, C, F, 1, nullptr, 0, {term(L.S, 1, C, 0, L.dA0, F, 1, 0, C)});
+            add_task(b, gr.cheb_w1, F, 1, 0, C, F, 1, nullptr, 0,
+                     {term(p.region_w + (long)lo * C, 1, RC, C, L.dAall + (long)lo * C * F, F, 1, (long)C * F, C, hi - lo, 1)});
+            add_task(b, gr.cheb_bias, 1, 0, 0, C, 1, 1, nullptr, 0, {term(L.S, 1, C, 0, L.dbprime, 1, 0, 0, C)});
             add_task(b, gr.region_b, 1, 0, 0, C, 1, 1, L.dbprime, 1, {});
         }
         TRY(launch_small_gemm_multi(b, st));

@@ -288,6 +288,26 @@ int launch_head2_wgrad(const float* dpred, const float* y1, float* slab, int N, 
     return REGT_OK;
 }
 
+// S = sum over the R column blocks of the region linear layer (C x R*C): every composition that touches "all regions"
+// (A0, b', dW0, db_c) goes through S, so their cost does not grow with the region count of a multi-GPU graph.
+__global__ __launch_bounds__(256) void sum_region_blocks_kernel(const float* __restrict__ W, float* __restrict__ S, int C, int R) {
+    const long total = (long)C * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long i = e / C, j = e - i * C;
+        const float* w = W + i * (long)R * C + j;
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += w[(long)r * C];
+        S[e] = s;
+    }
+}
+int launch_sum_region_blocks(const float* W, float* S, int C, int R, hipStream_t st) {
+    int blocks = cdiv((long)C * C, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sum_region_blocks_kernel, dim3(blocks), dim3(256), 0, st, W, S, C, R);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 // loss = scale * sum (pred - y)^2 ;  dpred = 2 * scale * (pred - y)     (scale = 1 / (N_global * O))
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* y, float* dpred, float* loss_out,
                                                        long n, float scale) {

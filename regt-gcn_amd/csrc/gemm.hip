@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
         s += __shfl_xor(s, 4, 64);
     }
     if (valid && sub == 0) {
-        if (T.init) s += T.init[(long)i * T.init_si];
+        if (T.init) s += T.init[(long)i * T.init_si + (long)j * T.init_sj];
         T.C[(long)b * T.scb + (long)i * T.sci + (long)j * T.scj] = s;
     }
 }

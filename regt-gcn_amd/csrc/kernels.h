@@ -109,7 +109,8 @@ struct SgTerm {
 struct SgTask {
     float* C; long sci, scj, scb;
     int m, n, nbatch;            // output (nbatch, m, n)
-    const float* init; long init_si;   // optional init[i*init_si] added to every column (nullptr: 0)
+    const float* init; long init_si;   // optional init[i*init_si + j*init_sj] added to the sum (nullptr: 0; init_sj = 0:
+    long init_sj;                      // the same value for every column)
     int nterm;
     SgTerm term[3];
     int split;                   // lanes per output element (set by launch_small_gemm_multi: 1 for short sums, 8 for long ones)
@@ -153,6 +154,8 @@ int launch_head2_fwd(const float* y1, const float* W2, const float* b2, float* p
 int launch_head2_bwd(const float* dpred, const float* W2, const float* y1, float* d1, int N, int H1, int O, hipStream_t st);
 int launch_head2_wgrad(const float* dpred, const float* y1, float* slab, int N, int H1, int O, int kchunk, int nchunks, int colsum,
                        hipStream_t st);
+// S[i, j] = sum_r W[i, r*C + j]: the sum of the R (C x C) blocks of tgnn.linear.weight (cell.hip)
+int launch_sum_region_blocks(const float* W, float* S, int C, int R, hipStream_t st);
 int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {
     const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;

@@ -218,7 +218,9 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     rp_l, col_l, val_l = raw_csr(torch.cat(loc_idx, dim=1), torch.cat(w_all), n_loc)
     nnz_a = int(col_a.numel())
     m = merge_operators(rp_a, col_a, val_a, rp_l, col_l, val_l, n_loc)
-    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(region_index), m_rowptr=m[0], m_col=m[1], m_val_a=m[2], m_val_l=m[3],
+    contiguous = mine == list(range(mine[0], mine[-1] + 1)) if mine else False
+    graph = PreparedGraph(num_nodes=n_loc, num_regions=len(region_index), region_lo=mine[0] if contiguous else 0,
+                          region_hi=mine[-1] + 1 if contiguous else 0, m_rowptr=m[0], m_col=m[1], m_val_a=m[2], m_val_l=m[3],
                           rowptr=torch.cat([rp_a, rp_l[1:] + nnz_a]).contiguous(),
                           col=torch.cat([col_a, col_l]).contiguous(), val=torch.cat([val_a, val_l]).contiguous(),
                           node_region=torch.from_numpy(owner).to(device), node_region_host=owner,

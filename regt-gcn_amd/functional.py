@@ -99,6 +99,7 @@ def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
         g.m_rowptr, g.m_col = graph.m_rowptr.data_ptr(), graph.m_col.data_ptr()
         g.m_val_a, g.m_val_l = graph.m_val_a.data_ptr(), graph.m_val_l.data_ptr()
     g.overlap = 1 if graph.overlap else 0
+    g.region_lo, g.region_hi = graph.region_lo, graph.region_hi
     return g
 
 

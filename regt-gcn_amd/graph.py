@@ -33,6 +33,8 @@ class PreparedGraph:
     nnz_gcn: int
     nnz_cheb: int
     # merged operator (one entry per distinct (row, col) with both weights) for the single-gather SpMM
+    region_lo: int = 0             # region ids [region_lo, region_hi) own rows of this graph; 0, 0 = all (dist.build_shard
+    region_hi: int = 0             # sets the owned block of a region shard)
     m_rowptr: Optional[torch.Tensor] = None
     m_col: Optional[torch.Tensor] = None
     m_val_a: Optional[torch.Tensor] = None
