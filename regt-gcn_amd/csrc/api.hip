@@ -577,7 +577,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(rq.push(r0));
         WgradReduceArgs r1{};
         r1.slab = a.slab; r1.nchunks = g.n_chunks; r1.slab_stride = wgrad_slab_stride(a); r1.elem_offset = F; r1.slab_ld = 2 * F;
-        r1.Nout = C; r1.Nin = F; r1.chunk_group = g.chunk_region; r1.ngroups = R; r1.out = dAall; r1.ldo = F;
+        int lo, hi;
+        region_range(d, g, &lo, &hi);           // only the owned region blocks have rows here (and are read later)
+        r1.Nout = C; r1.Nin = F; r1.chunk_group = g.chunk_region; r1.ngroups = hi - lo; r1.group_base = lo;
+        r1.out = dAall + (long)lo * C * F; r1.ldo = F;
         r1.group_stride = (long)C * F;
         TRY(rq.push(r1));
     }

@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long
                 e = idx - (long)g * per;
                 const long se = a.slab_ld ? (e / a.Nin) * a.slab_ld + e % a.Nin : e;
                 for (int c = sub; c < a.nchunks; c += 8)
-                    if (!a.chunk_group || a.chunk_group[c] == g) s += a.slab[(long)c * a.slab_stride + a.elem_offset + se];
+                    if (!a.chunk_group || a.chunk_group[c] == g + a.group_base) s += a.slab[(long)c * a.slab_stride + a.elem_offset + se];
             } else {
                 for (int c = sub; c < a.nchunks; c += 8) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + (idx - total)];
             }

@@ -70,7 +70,8 @@ struct WgradReduceArgs {
     long slab_ld;             // row stride of that block inside a slab (0: dense, = Nin)
     int Nout, Nin;
     const int* chunk_group;   // optional (nchunks): output group of each chunk
-    int ngroups;
+    int ngroups;              // groups group_base .. group_base + ngroups - 1 are reduced (into out blocks 0 .. ngroups - 1)
+    int group_base;
     float* out; long ldo; long group_stride;   // out[g*group_stride + i*ldo + j]
     float* colsum_out;        // optional (ncolsum), only ngroups == 1
     long colsum_offset;       // slab element of the first column sum
