@@ -344,7 +344,9 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         S.seg[1].nrep = R;
         S.node_region = g.node_region;
         S.row_div = T;
-        S.num_regions = R;
+        int lo, hi;
+        region_range(d, g, &lo, &hi);
+        S.num_regions = hi - lo;                 // a row tile can only meet the regions that own rows here
         EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
         PROF("gemm_regional", st);
         TRY(launch_gemm_bias_act(S, M, C, e, st));
