@@ -90,6 +90,9 @@ class _WsHandle:
 
 
 def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
+    cache = graph.__dict__.setdefault("_struct_cache", {})       # the struct only holds pointers into the graph's own tensors
+    if periods in cache:
+        return cache[periods]
     tab, reg, n = graph.chunks_for(periods)
     g = _lib.Graph()
     g.rowptr, g.col, g.val = graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.val.data_ptr()
@@ -100,6 +103,7 @@ def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
         g.m_val_a, g.m_val_l = graph.m_val_a.data_ptr(), graph.m_val_l.data_ptr()
     g.overlap = 1 if graph.overlap else 0
     g.region_lo, g.region_hi = graph.region_lo, graph.region_hi
+    cache[periods] = g
     return g
 
 
@@ -166,6 +170,7 @@ class RegTGCNFunction(torch.autograd.Function):
                                         _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward")
         ctx.graph, ctx.regional, ctx.dims, ctx.ws, ctx.wsb = graph, regional, dims, ws, wsb
         ctx.ws_handle = handle
+        ctx.ps, ctx.gs = ps, gs                  # parameter / graph pointer structs: unchanged until backward
         ctx.xp = x if packed else None
         ctx.names = names
         ctx.save_for_backward(hidden, *params)
@@ -182,11 +187,15 @@ class RegTGCNFunction(torch.autograd.Function):
             dpred = torch.zeros(dims.N, dims.O, dtype=torch.float32, device=dev)
         dpred = dpred.contiguous()
         dhid = None if dhidden is None else dhidden.contiguous()
-        grads = {n_: torch.empty_like(p_) for n_, p_ in tens.items()}
-        gs = _graph_struct(ctx.graph, dims.T)
-        ps = _fill(_lib.Params(), tens, regional)
+        # one allocation for all gradients (16-byte aligned views), not one per parameter
+        sizes = [(p_.numel() + 3) & ~3 for p_ in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = {}, 0
+        for n_, p_, sz in zip(names, params, sizes):
+            grads[n_] = flat[off:off + p_.numel()].view_as(p_)
+            off += sz
         gr = _fill(_lib.Grads(), grads, regional)
-        _lib.check(lib.regt_backward(C.byref(dims), C.byref(gs), C.byref(ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
+        _lib.check(lib.regt_backward(C.byref(dims), C.byref(ctx.gs), C.byref(ctx.ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
                                      _lib.ptr(hidden), _lib.ptr(ctx.xp), _lib.ptr(ctx.ws), ctx.wsb, _stream()), "regt_backward")
         return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
 
