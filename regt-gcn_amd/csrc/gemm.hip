@@ -326,50 +326,46 @@ int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, 
 // Per period t: Ht = tanh(q_t Uh2^T + (A_hat x)_t Gh^T + ch) is stored for the backward pass, blended
 // with the gate (Z*h + (1-Z)*Ht) and accumulated with the attention probability p_t in registers;
 // the hidden state (N, C) is written once after the last period.
-template <bool VEC>
+// Generic (scalar-epilogue) fallback of the candidate stage: one workgroup walks the T periods of a node tile.
 __global__ __launch_bounds__(256, 1) void gemm_cand_kernel(CandArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (a.C + GBN - 1) / GBN;
     const long C = a.C;
     f32x16 acc[2][2];
-    if constexpr (VEC) {
-        // the vector path lives in gemm_cand_flat_kernel
-    } else {
-        const int bid = xcd_remap(blockIdx.x, gridDim.x);
-        const int i0 = (bid / tiles_n) * GBM;
-        const int n0 = (bid % tiles_n) * GBN;
-        const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
-        f32x16 oh[2][2];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int i0 = (bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    const int nvalid = (a.num_nodes - i0) < GBM ? (a.num_nodes - i0) : GBM;
+    f32x16 oh[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oh[i][j][r] = 0.f;
+    for (int t = 0; t < a.T; ++t) {
+        RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
+        GemmCore core(a.S, rm, n0, a.C, lds);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oh[i][j][r] = 0.f;
-        for (int t = 0; t < a.T; ++t) {
-            RowMap rm{(long)i0 * a.T + t, a.T, nvalid};
-            GemmCore core(a.S, rm, n0, a.C, lds);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            core.run(acc);
-            const float pt = a.probs[t];
-            core.for_each2(acc, oh, [&](int r, int c, float v, float o) {
-                long m = rm.grow(r);
-                float ht = fast_tanh(v + a.bias[c]);
-                a.Ht[m * C + c] = ht;
-                float Z = a.ZR[m * 2 * C + c];
-                float hv = a.h[m * C + c];
-                return o + pt * (Z * hv + (1.0f - Z) * ht);
-            });
-        }
-        RowMap rm{(long)i0, 1, nvalid};
-        GemmCore core(a.S, rm, n0, a.C, lds);
-        core.for_each(oh, [&](int r, int c, float v) { a.OH[(long)(i0 + r) * C + c] = v; });
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        core.run(acc);
+        const float pt = a.probs[t];
+        core.for_each2(acc, oh, [&](int r, int c, float v, float o) {
+            long m = rm.grow(r);
+            float ht = fast_tanh(v + a.bias[c]);
+            a.Ht[m * C + c] = ht;
+            float Z = a.ZR[m * 2 * C + c];
+            float hv = a.h[m * C + c];
+            return o + pt * (Z * hv + (1.0f - Z) * ht);
+        });
     }
+    RowMap rm{(long)i0, 1, nvalid};
+    GemmCore core(a.S, rm, n0, a.C, lds);
+    core.for_each(oh, [&](int r, int c, float v) { a.OH[(long)(i0 + r) * C + c] = v; });
 }
 
 // Vector path of the candidate stage: a FLAT GEMM over the (node*T + t) rows, same geometry and
@@ -473,8 +469,8 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_cand_flat_kernel<FastCore<true, false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
         static bool attr_done2 = false;
-        if (int rc = set_lds_once(&gemm_cand_kernel<false>, G_LDS_BYTES, &attr_done2)) return rc;
-        hipLaunchKernelGGL(gemm_cand_kernel<false>, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
+        if (int rc = set_lds_once(&gemm_cand_kernel, G_LDS_BYTES, &attr_done2)) return rc;
+        hipLaunchKernelGGL(gemm_cand_kernel, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
     }
     REGT_CHECK_LAUNCH();
     return REGT_OK;
