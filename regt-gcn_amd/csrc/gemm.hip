@@ -1,10 +1,14 @@
-// Dense contractions of the RegT-GCN pipeline on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+// Dense contractions of the RegT-GCN pipeline on the matrix cores.
 //
-//   gemm_flat_kernel<Epi>   C = sum_seg A_seg B_seg^T with a fused epilogue   (forward + dgrad)
-//   gemm_cand_kernel        candidate state + GRU blend + attention-weighted sum over T periods
-//   wgrad_kernel<..>        out = P^T Q over row chunks (weight gradients), partial slabs
-//   wgrad_reduce_kernel     deterministic reduction of the slabs
-//   small_gemm_kernel       strided batched C = A B for the (C x F)-sized weight compositions
+//   gemm_flat_fast_kernel<Epi, Core>   C = sum_seg A_seg B_seg^T with a fused epilogue (forward + data gradients);
+//                                      Core = FastCore (fp32 v_mfma_f32_32x32x2_f32, gemm_fast.h) or SplitCore (exact
+//                                      3-way bf16 split on v_mfma_f32_32x32x16_bf16, gemm_split.h; opt-in)
+//   gemm_flat_small_kernel<Epi, ..>    the same with 64 x 64 tiles for problems of fewer than 128 big tiles (gemm_small.h)
+//   gemm_flat_kernel<Epi>              generic fallback (operands that are not 16-byte tileable)
+//   gemm_cand_flat_kernel<Core>        candidate state + GRU blend + attention-weighted sum over the T periods
+//   wgrad_kernel<BNW> / wgrad_split_kernel   out = P^T Q over row chunks (weight gradients), partial slabs
+//   wgrad_reduce(_multi)_kernel        deterministic reduction of the slabs (all of a backward pass in one launch)
+//   small_gemm_multi_kernel            strided batched C = A B for the (C x F)-sized weight compositions
 #include "kernels.h"
 #include "gemm_fast.h"
 #include "gemm_split.h"
