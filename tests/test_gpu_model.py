@@ -367,3 +367,42 @@ def test_fused_train_step_equals_autograd_path(R, tpims, model_name):
     stepper.zero_grad()
     assert all(float(p.grad.abs().max()) == 0.0 for p in fused.parameters() if p.grad is not None)
     float(stepper(xs[0], ys[0]))                                    # parameters updated in place: the stepper keeps working
+
+
+def test_hipgraph_replay_path_matches_goldens():
+    """REGT_HIPGRAPH=1 (opt-in, read at first use -> needs its own process): the captured forward / backward launch
+    sequences replay to the same numbers as eager launches, and the third call really is a replay."""
+    import subprocess
+    import sys
+    script = r'''
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import regtgcn_amd as R
+from regtgcn_amd import _lib
+from oracle import model as M
+d = np.load("tests/golden/tpims_fixture.npz"); fx = {k: torch.from_numpy(d[k]) for k in d.files if d[k].ndim > 0}
+g = np.load("tests/golden/golden_regt_in6_out1.npz")
+regs = ("IA", "KS", "KY", "OH", "WI")
+n, t_in, t_out = fx["node_data"].shape[0], 6, 1
+mod = R.RegionalTemporalGCN(8, n, t_in, t_out)
+mod.load_state_dict(M.init_params("RegionalTemporalGCN", 8, t_in, t_out, num_nodes=n, seed=int(g["seed"])))
+mod = mod.cuda()
+graph = mod.prepare_graph(fx["edge_index"].cuda(), [fx[f"edge_{r}_index"].cuda() for r in regs], [fx[f"edge_{r}_attr"].cuda() for r in regs])
+x = fx["node_data"][:, :, :t_in].contiguous().cuda(); y = fx["node_data"][:, -1, t_in:t_in + t_out].contiguous().cuda()
+for it in range(3):
+    mod.zero_grad()
+    pred, hid = mod.forward_prepared(x, graph)
+    torch.mean((pred - y) ** 2).backward()
+    assert np.abs(pred.detach().cpu().numpy() - g["pred"]).max() < 1e-5, it
+    assert np.abs(hid.detach().cpu().numpy() - g["hidden"]).max() < 1e-5, it
+    gw = mod.linear1.weight.grad.cpu().numpy()
+    assert np.abs(gw.sum(1) - g["grow__linear1__weight"]).max() < 1e-4, it
+st = (ctypes.c_int64 * 6)(); _lib.load().regt_graph_stats(st)
+assert st[2] >= 1 and st[5] >= 1, list(st)
+print("OK", list(st))
+'''
+    env = dict(os.environ, REGT_HIPGRAPH="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", script], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
