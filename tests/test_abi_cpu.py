@@ -57,3 +57,37 @@ def test_modules_refuse_cpu_tensors_and_keep_reference_layout():
     assert not any(k.startswith("tgnn._weight_att") for k in t.state_dict())
     import inspect
     assert list(inspect.signature(t.forward).parameters) == ["x", "edge_index", "edge_attr"]   # keyword call, run.py:188
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
+    """Every model-level entry point validates dims / pointers / alignment on the host and reports through
+    regt_last_error (the reference raises Python exceptions at the same places: wrong shapes, missing tensors)."""
+    lib = R.load_library()
+    B = ctypes.byref
+    good = _lib.Dims(104, 6, 8, 256, 5, 1, 128, 1, 0.01)
+    g, p, gr = _lib.Graph(), _lib.Params(), _lib.Grads()
+    one = ctypes.c_void_p(256)                                    # a non-NULL, 16-byte aligned dummy that is never dereferenced
+
+    rc = lib.regt_forward(None, B(g), B(p), one, one, one, one, 1 << 30, None)
+    assert rc != 0 and b"dims is NULL" in lib.regt_last_error()
+    rc = lib.regt_forward(B(good), B(g), B(p), one, one, one, one, 1 << 30, None)
+    assert rc != 0 and b"graph incomplete" in lib.regt_last_error()
+    g.rowptr = g.col = g.val = g.node_region = 256
+    rc = lib.regt_forward(B(good), B(g), B(p), one, one, one, one, 1 << 30, None)
+    assert rc != 0 and b"required tensor pointer is NULL" in lib.regt_last_error()
+    bad_t = _lib.Dims(104, 65, 8, 256, 5, 1, 128, 1, 0.01)
+    rc = lib.regt_forward(B(bad_t), B(g), B(p), one, one, one, one, 1 << 30, None)
+    assert rc != 0 and b"exceeds 64 periods" in lib.regt_last_error()
+    rc = lib.regt_cell_forward(B(good), B(g), B(p), one, one, one, one, one, 1 << 30, None)
+    assert rc != 0 and b"regional must be 0" in lib.regt_last_error()
+    rc = lib.regt_backward(B(good), B(g), B(p), None, one, None, one, None, one, 1 << 30, None)
+    assert rc != 0                                                 # params incomplete / grads NULL
+    rc = lib.regt_spmm_csr(one, one, one, one, one, 8, 8, 6, None)
+    assert rc != 0 and b"multiple of 4" in lib.regt_last_error()
+    rc = lib.regt_spmm_dual(one, one, one, one, one, one, one, 8, 48, None)
+    assert rc != 0 and b"multiple of 32" in lib.regt_last_error()
+    rc = lib.regt_linear(one, 8, 4, 8, one, 8, 4, None, 7, 0.0, one, 4, None)
+    assert rc != 0 and b"act must be" in lib.regt_last_error()
+    rc = lib.regt_wgrad(one, 4, one, 8, 16, 4, 8, one, 8, None, None, None)
+    assert rc != 0 and b"bad argument" in lib.regt_last_error()
+    assert lib.regt_set_gemm_mode(0) in (0, 1)
