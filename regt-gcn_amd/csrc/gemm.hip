@@ -193,6 +193,28 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
     core.for_each_vec(acc, epi);
 }
 
+// Split core with the compact LDS layout (two bf16 stages + table, epilogue in two 64-row halves): three workgroups per CU.
+template <class EpiF, bool REGION>
+__global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    SplitCore<REGION> core(S, rm, n0, N, lds, true);
+    core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    core.run(acc, relu_a != 0);
+    core.for_each_vec_halves(acc, epi);
+}
+
 // Small problems: 64 x 64 tiles (gemm_small.h) -- same operands, segments and epilogues, a quarter of the work per tile.
 template <class EpiF, bool BT, bool REGION>
 __global__ __launch_bounds__(256, 4) void gemm_flat_small_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
@@ -271,7 +293,13 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
         return REGT_OK;
     }
     if constexpr (BT) {
-        if (gemm_mode() == 1) return launch_fast_core<EpiF, SplitCore<REGION>>(S, M, N, f, relu, st);
+        if (gemm_mode() == 1) {
+            const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
+            REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
+            hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION>), dim3((unsigned)tiles), dim3(256), SP_LDS_BYTES, st, S, M, N, f, relu);
+            REGT_CHECK_LAUNCH();
+            return REGT_OK;
+        }
     }
     return launch_fast_core<EpiF, FastCore<BT, REGION>>(S, M, N, f, relu, st);
 }
