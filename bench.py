@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every GPU owns a full workload-sized shard (global graph N times larger, the default "
                          "the driver measures); strong = the ONE workload graph split by regions across the GPUs")
+    ap.add_argument("--force-shard-path", action="store_true",
+                    help="N = 1 only: run the region-shard code path (packed input, halo pipeline, RCCL calls) with a 1-rank "
+                         "process group -- a rehearsal of what N > 1 executes, not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3-split measurement")
     ap.add_argument("--no-tpims-leg", action="store_true", help="skip the secondary TPIMS-scale (configs[1]) measurement")
@@ -192,7 +195,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_shard = args.force_shard_path and world == 1
+    if force_shard:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        os.environ["REGT_DIST_FORCE"] = "1"          # collectives run even though the group has one rank
+    if world > 1 or force_shard:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -226,7 +234,7 @@ def main():
     xs = [x.to(dev) for x, _ in snaps]
     ys = [y.to(dev) for _, y in snaps]
     del snaps
-    if world == 1:
+    if world == 1 and not force_shard:
         graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index],
                                 [t.to(dev) for t in g.region_attr], nodes)
         shard = None
@@ -263,7 +271,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_shard:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -315,7 +323,7 @@ def main():
         loss = None                         # let the headline model's workspaces go back to the pool
         tpims = tpims_leg(dev, with_cpu=not args.no_cpu_baseline)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if world > 1 or force_shard:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -374,7 +382,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(nodes, edges, regions, F, T, O)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_shard:
         dist.destroy_process_group()
 
 

@@ -17,6 +17,7 @@ The reference is single-process; this layer is
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -95,6 +96,11 @@ def shard_topology(edge_index: np.ndarray, owner_bounds: np.ndarray, rank: int, 
     return ShardTopology(rank, world, int(owner_bounds[rank]), int(owner_bounds[rank + 1]), need, send)
 
 
+# Rehearsal aid (bench.py --force-shard-path): issue the collectives even in a 1-rank group, so that the exact RCCL calls
+# of the N > 1 flow can be exercised on a one-GPU box.
+_FORCE_COLLECTIVES = os.environ.get("REGT_DIST_FORCE") == "1"
+
+
 def exchange_boundary_rows(xp_ext: torch.Tensor, topo: ShardTopology, send_idx: torch.Tensor, group=None):
     """Fill rows [n_local, x_rows) of ``xp_ext`` (in place) with the halo rows, one all-to-all: every rank sends
     each peer exactly the rows that peer's in-edges read.  xGMI is point-to-point, so the personalised exchange
@@ -102,7 +108,7 @@ def exchange_boundary_rows(xp_ext: torch.Tensor, topo: ShardTopology, send_idx: 
 
     ``xp_ext``: (x_rows, W) with the rank's own packed rows already in [0, n_local).  Works with the
     'nccl' (RCCL) backend on GPU tensors and with 'gloo' on CPU tensors (tests)."""
-    if topo.world == 1:
+    if topo.world == 1 and not _FORCE_COLLECTIVES:
         return xp_ext
     send = xp_ext.index_select(0, send_idx)                       # (sum send_splits, W)
     recv = xp_ext[topo.n_local:]                                   # (halo_rows, W), contiguous view
@@ -160,7 +166,7 @@ class HaloPipeline:
 
 def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum all-reduce; a GPU tensor under the 'gloo' rehearsal backend is staged through the host."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return t
     if t.is_cuda and dist.get_backend(group) == "gloo":
         host = t.cpu()
@@ -174,7 +180,7 @@ def allreduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
 def allreduce_gradients(params: Sequence[torch.nn.Parameter], group=None):
     """One flat-buffer sum all-reduce of all gradients (3-19 MB here: latency-bound on xGMI, so one call)."""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not grads or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE_COLLECTIVES):
         return
     flat = allreduce_sum(torch.cat([g.reshape(-1) for g in grads]), group)
     off = 0
