@@ -507,7 +507,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
     }
     // The split core takes weights as [N][K] only: give the data gradients transposed copies of the three C x C blocks.
-    const bool split = gemm_mode() == 1;
+    const bool split = gemm_mode() != 0;
     if (split) {
         PROF("transpose_gate_w", st);
         TRY(launch_transpose3(p.gate_w[2] + C, p.gate_w[0] + C, p.gate_w[1] + C, 3, L.UT, C, C, 2L * C, st));

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
 }
 
 // Split core with the compact LDS layout (two bf16 stages + table, epilogue in two 64-row halves): three workgroups per CU.
-template <class EpiF, bool REGION>
+// NP = 3: exact 3-way split (fp32-level accuracy); NP = 1: plain bf16 operands, fp32 accumulate (REGT_GEMM_MODE=bf16).
+template <class EpiF, bool REGION, int NP>
 __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
     const long m0 = (long)(bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
-    SplitCore<REGION> core(S, rm, n0, N, lds, true);
+    SplitCore<REGION, NP> core(S, rm, n0, N, lds, true);
     core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -233,16 +234,19 @@ __global__ __launch_bounds__(256, 4) void gemm_flat_small_kernel(GemmSegs S, lon
 }
 
 // 0: fp32 MFMA (default).  1: exact 3-way bf16 split of both operands, six partial products on the bf16 matrix pipe
-// (gemm_split.h) for the GEMMs whose B operand is stored [N][K].
+// (gemm_split.h) for the GEMMs whose B operand is stored [N][K].  2: plain bf16 operands (one product), fp32 accumulate --
+// reduced precision, the arithmetic BASELINE configs[4] names.
 static int g_gemm_mode = -1;
 int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("REGT_GEMM_MODE");
-        g_gemm_mode = (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) ? 1 : 0;
+        g_gemm_mode = 0;
+        if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_gemm_mode = 1;
+        if (e && (!strcmp(e, "bf16") || !strcmp(e, "2"))) g_gemm_mode = 2;
     }
     return g_gemm_mode;
 }
-void set_gemm_mode(int m) { g_gemm_mode = m ? 1 : 0; }
+void set_gemm_mode(int m) { g_gemm_mode = (m == 1 || m == 2) ? m : 0; }
 
 // 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
 static int fast_class(const GemmSegs& S, int N, bool vec) {
@@ -260,9 +264,17 @@ static int fast_class(const GemmSegs& S, int N, bool vec) {
         if (b && g.nsplit < N && g.nsplit % GBN != 0) return -1;      // a column tile must not straddle B0 | B1
         if (g.lda >= (1L << 22) || g.ldb >= (1L << 22)) return -1;    // 32-bit byte offsets inside a tile
         if ((g.flags & SEG_REPEAT) && g.a_rep_stride % 4 != 0) return -1;
-        // worst case: a row tile touches every region (node ids not sorted by region)
-        iters += (long)cdiv(g.K, GBK) * ((g.flags & SEG_REGION) ? (S.num_regions > 0 ? S.num_regions : 1)
-                                                                 : ((g.flags & SEG_REPEAT) ? g.nrep : 1));
+        // worst case of a region-masked segment: every node of a row tile lies in another region (node ids not sorted by
+        // region) -- a 128-row tile of node-major rows meets at most 128 / row_div + 2 nodes; never more than all regions
+        long reps = 1;
+        if (g.flags & SEG_REGION) {
+            const long by_rows = GBM / (S.row_div > 0 ? S.row_div : 1) + 2;
+            reps = S.num_regions > 0 ? S.num_regions : 1;
+            if (by_rows < reps) reps = by_rows;
+        } else if (g.flags & SEG_REPEAT) {
+            reps = g.nrep;
+        }
+        iters += (long)cdiv(g.K, GBK) * reps;
     }
     if (relu && S.nseg != 1) return -1;
     if (iters > G_MAX_ITERS) return -1;
@@ -293,10 +305,13 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
         return REGT_OK;
     }
     if constexpr (BT) {
-        if (gemm_mode() == 1) {
+        if (gemm_mode() != 0) {
             const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
             REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-            hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION>), dim3((unsigned)tiles), dim3(256), SP_LDS_BYTES, st, S, M, N, f, relu);
+            if (gemm_mode() == 1)
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 3>), dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, f, relu);
+            else
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 1>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, relu);
             REGT_CHECK_LAUNCH();
             return REGT_OK;
         }
@@ -485,15 +500,18 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias) &&
                      fast_class(a.S, a.C, true) == 1;
     if (vec) {
-        static bool attr_done = false, attr_done_split = false;
+        static bool attr_done = false, attr_done_split = false, attr_done_bf16 = false;
         if (int rc = set_lds_once(&gemm_cand_flat_kernel<FastCore<true, false>>, G_FAST_LDS_BYTES, &attr_done)) return rc;
-        if (int rc = set_lds_once(&gemm_cand_flat_kernel<SplitCore<false>>, G_FAST_LDS_BYTES, &attr_done_split)) return rc;
+        if (int rc = set_lds_once(&gemm_cand_flat_kernel<SplitCore<false, 3>>, G_FAST_LDS_BYTES, &attr_done_split)) return rc;
+        if (int rc = set_lds_once(&gemm_cand_flat_kernel<SplitCore<false, 1>>, G_FAST_LDS_BYTES, &attr_done_bf16)) return rc;
         const long M = (long)a.num_nodes * a.T;
         const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
         REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
         if (gemm_mode() == 1)
-            hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+            hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 3>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        else if (gemm_mode() == 2)
+            hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 1>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
         else if (ftiles < SMALL_TILE_LIMIT)      // small graph: 64 x 64 tiles (a node's T <= 64 rows still span at most two)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SmallCore<true, false>>), dim3((unsigned)(cdiv(M, SM_B) * cdiv(a.C, SM_B))),
                                dim3(256), SM_LDS_BYTES, st, a);
@@ -697,12 +715,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // ds_read_b64_tr_b16, the transposing LDS read that hands every lane 4 consecutive k of one column: two of them per
 // plane make the 8-k operand of v_mfma_f32_32x32x16_bf16 without any shuffle.
 constexpr int WS_PLANE_B = 16 * 256;             // one plane of one operand of one half slab
-constexpr int WS_OPER_B = 3 * WS_PLANE_B;        // 12288
-constexpr int WS_STAGE_B = 2 * WS_OPER_B;        // 24576: P planes, then Q planes
-constexpr int WS_LDS_BYTES = 2 * WS_STAGE_B;     // 49152
 __device__ __forceinline__ int ws_off(int m, int ch) { return 256 * m + 16 * (ch ^ (((m & 3) << 2) | ((m >> 2) & 3))); }
 
+template <int NP>   // 3: exact 3-way split, six partial products; 1: plain bf16 operands, one product (REGT_GEMM_MODE=bf16)
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
+    constexpr int WS_OPER_B = NP * WS_PLANE_B;       // 12288 / 4096
+    constexpr int WS_STAGE_B = 2 * WS_OPER_B;        // P planes, then Q planes
+    constexpr int WS_RED_B = 256 * 16;               // column-sum reduction image
+    static_assert(2 * WS_STAGE_B >= WS_RED_B, "column-sum image fits the stages");
     using Core = FastCore<true, false>;
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -769,11 +789,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
             q.x = fmaxf(q.x, qfloor); q.y = fmaxf(q.y, qfloor); q.z = fmaxf(q.z, qfloor); q.w = fmaxf(q.w, qfloor);
             csum.x += p.x; csum.y += p.y; csum.z += p.z; csum.w += p.w;
             const int off = ws_off((tid >> 5) + 8 * j, c4 >> 1) + 8 * (c4 & 1);
-            SplitCore<false>::split_store(st + off, p, WS_PLANE_B);
-            SplitCore<false>::split_store(st + WS_OPER_B + off, q, WS_PLANE_B);
+            SplitCore<false, NP>::split_store(st + off, p, WS_PLANE_B);
+            SplitCore<false, NP>::split_store(st + WS_OPER_B + off, q, WS_PLANE_B);
         }
     };
-    struct Frags { bf16x8 a[2][3], b[2][3]; };
+    struct Frags { bf16x8 a[2][NP], b[2][NP]; };
     // lane 4q+p of a 16-lane group addresses block row q, columns 4p..4p+3; the group receives 4 k x 16 columns
     // transposed.  Groups 0,1 take columns 0-15 / 16-31 of the 32-column tile at k = 0..3, groups 2,3 the same
     // columns at k = 8..11; a second read 4 rows further down completes the 8-k operand.
@@ -787,7 +807,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
             const int cb = (wc * 64 + t * 32 + 16 * (gg & 1) + 4 * gp) >> 3;
             const int sub = 8 * (gp & 1);
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 s16x4 lo, hi;
                 const int m0 = 8 * (gg >> 1) + gq;
                 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + p * WS_PLANE_B + ws_off(m0, ca) + sub));
@@ -801,9 +821,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
         return f;
     };
     auto mfmas = [&](const Frags& f) {
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int PA[6] = {NP == 3 ? 2 : 0, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < (NP == 3 ? 6 : 1); ++q)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -816,13 +836,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
         store_half(hs, rp, rq);
         mfmas(f);
         load_half(hs, k_next, live, rp, rq);
-        __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
+        if (NP == 3) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 24, 0);
 #pragma unroll
-        for (int r = 0; r < 24; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            for (int r = 0; r < 24; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -1009,10 +1040,13 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
                       (!a.Q2 || (a.ldq2 % 4 == 0 && a.ldq2 < (1L << 20) && a16(a.Q2) && a.nin_split % 32 == 0));
     REGT_CHECK_ARG(!a.Q2 || fast, "wgrad: a second right-hand operand needs 16-byte tileable operands and nin_split %% 32 == 0");
     if (wide) {
-        static bool attr_done = false, attr_done_g = false, attr_done_s = false;
+        static bool attr_done = false, attr_done_g = false, attr_done_s = false, attr_done_b = false;
         if (fast && gemm_mode() == 1) {
-            if (int rc = set_lds_once(&wgrad_split_kernel, WS_LDS_BYTES, &attr_done_s)) return rc;
-            hipLaunchKernelGGL(wgrad_split_kernel, dim3((unsigned)blocks), dim3(256), WS_LDS_BYTES, st, a);
+            if (int rc = set_lds_once(&wgrad_split_kernel<3>, 4 * 3 * WS_PLANE_B, &attr_done_s)) return rc;
+            hipLaunchKernelGGL(wgrad_split_kernel<3>, dim3((unsigned)blocks), dim3(256), 4 * 3 * WS_PLANE_B, st, a);
+        } else if (fast && gemm_mode() == 2) {
+            if (int rc = set_lds_once(&wgrad_split_kernel<1>, 4 * 1 * WS_PLANE_B, &attr_done_b)) return rc;
+            hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), 4 * 1 * WS_PLANE_B, st, a);
         } else if (fast) {
             if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
             hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);

@@ -27,6 +27,36 @@ struct ItDesc {
 constexpr int G_TABLE_BYTES = G_MAX_ITERS * (int)sizeof(ItDesc);
 constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
 
+// Sorted list of the DISTINCT regions among a tile's rows, built by thread 0 in LDS (red[8 ..): region of each row, then the
+// list; red[3] = its length).  A region-masked segment is repeated once per listed region only, so the iteration count is
+// bounded by the regions a tile can meet (its node count + 1 for node-major rows), not by the region count of the graph --
+// 64 regions (the 8-GPU global graph on one GPU) stay on the fast path.  Ascending order = the order of the old
+// [rmin, rmax] walk minus the regions that contributed only zeros, so sums are unchanged bit for bit.
+template <int BMT>
+__device__ __forceinline__ const int* tile_regions(const GemmSegs& S, const RowMap& rm, int* red, int tid) {
+    int* rowreg = red + 8;
+    int* list = red + 8 + BMT;
+    if (tid < BMT && tid < rm.nvalid) rowreg[tid] = S.node_region[rm.grow(tid) / S.row_div];
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0, last = -1;
+        const int nv = rm.nvalid < BMT ? rm.nvalid : BMT;
+        for (int r = 0; r < nv; ++r) {
+            const int reg = rowreg[r];
+            if (reg == last) continue;
+            last = reg;
+            int pos = 0;
+            while (pos < n && list[pos] < reg) ++pos;
+            if (pos < n && list[pos] == reg) continue;
+            for (int j = n; j > pos; --j) list[j] = list[j - 1];
+            list[pos] = reg;
+            ++n;
+        }
+        red[3] = n;
+    }
+    return list;        // valid for thread 0 (the table builder) only
+}
+
 template <bool BT, bool REGION>
 struct FastCore {
     // tile geometry seen by kernels with their own epilogue (candidate kernel)
@@ -79,29 +109,19 @@ struct FastCore {
 
     // Build the iteration table (one thread), return its length to everybody.  Ends with a barrier.
     __device__ __forceinline__ void plan() {
-        int rmin = 0, rmax = 0;
         int* red = reinterpret_cast<int*>(lds);
-        if (REGION) {
-            if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
-            __syncthreads();
-            if (tid < GBM && tid < rm.nvalid) {
-                const int reg = S.node_region[rm.grow(tid) / S.row_div];
-                atomicMin(&red[0], reg);
-                atomicMax(&red[1], reg);
-            }
-            __syncthreads();
-            rmin = red[0];
-            rmax = red[1];
-            __syncthreads();
-        }
+        const int* rlist = nullptr;
+        if (REGION) rlist = tile_regions<GBM>(S, rm, red, tid);
         if (tid == 0) {
             int n = 0;
+            const int nreg = REGION ? red[3] : 0;
             for (int s = 0; s < S.nseg; ++s) {
                 const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
                 const bool reg = REGION && (g.flags & SEG_REGION);
                 const bool rep = (g.flags & SEG_REPEAT) != 0;
-                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : (rep ? g.nrep - 1 : 0);
-                for (int r = r0; r <= r1; ++r)
+                const int cnt = reg ? nreg : (rep ? g.nrep : 1);
+                for (int ri = 0; ri < cnt; ++ri) {
+                    const int r = reg ? rlist[ri] : ri;
                     for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
                         ItDesc d;
                         const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
@@ -110,6 +130,7 @@ struct FastCore {
                         d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
                         table[n++] = d;
                     }
+                }
             }
             red[2] = n;
         }

@@ -53,29 +53,19 @@ struct SmallCore {
 
     // iteration table: as FastCore::plan
     __device__ __forceinline__ void plan() {
-        int rmin = 0, rmax = 0;
         int* red = reinterpret_cast<int*>(lds);
-        if (REGION) {
-            if (tid == 0) { red[0] = 0x7fffffff; red[1] = -1; }
-            __syncthreads();
-            if (tid < SM_B && tid < rm.nvalid) {
-                const int reg = S.node_region[rm.grow(tid) / S.row_div];
-                atomicMin(&red[0], reg);
-                atomicMax(&red[1], reg);
-            }
-            __syncthreads();
-            rmin = red[0];
-            rmax = red[1];
-            __syncthreads();
-        }
+        const int* rlist = nullptr;
+        if (REGION) rlist = tile_regions<SM_B>(S, rm, red, tid);
         if (tid == 0) {
             int n = 0;
+            const int nreg = REGION ? red[3] : 0;
             for (int s = 0; s < S.nseg; ++s) {
                 const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
                 const bool reg = REGION && (g.flags & SEG_REGION);
                 const bool rep = (g.flags & SEG_REPEAT) != 0;
-                const int r0 = reg ? rmin : 0, r1 = reg ? rmax : (rep ? g.nrep - 1 : 0);
-                for (int r = r0; r <= r1; ++r)
+                const int cnt = reg ? nreg : (rep ? g.nrep : 1);
+                for (int ri = 0; ri < cnt; ++ri) {
+                    const int r = reg ? rlist[ri] : ri;
                     for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
                         ItDesc d;
                         const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
@@ -84,6 +74,7 @@ struct SmallCore {
                         d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
                         table[n++] = d;
                     }
+                }
             }
             red[2] = n;
         }

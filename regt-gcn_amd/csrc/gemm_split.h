@@ -32,23 +32,32 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SP_ROW_B = 32;                   // bytes of one (row, plane) of a 16-k half slab: two 16-B k-groups, no pad
 constexpr int SP_PLANE_B = 128 * SP_ROW_B;     // 4096
-constexpr int SP_OPER_B = 3 * SP_PLANE_B;      // 12288: three planes of one operand
-constexpr int SP_STAGE_B = 2 * SP_OPER_B;      // 24576: A planes, then B planes
-static_assert(2 * SP_STAGE_B <= 2 * G_STAGE * 4, "split stages fit the fp32 core's LDS footprint (table offset, epilogue image)");
-// LDS of a split-core workgroup that stages its epilogue in two 64-row halves (for_each_vec below): the two bf16 stages,
-// then the iteration table -- 54,528 B, so THREE workgroups fit a CU (163,840 B), which the 166-VGPR kernels also allow.
-constexpr int SP_TABLE_OFF_B = 2 * SP_STAGE_B;
-constexpr int SP_LDS_BYTES = SP_TABLE_OFF_B + G_TABLE_BYTES;
-static_assert(64 * G_LDS_KROW * 4 <= SP_TABLE_OFF_B, "half-tile epilogue image fits below the table");
+// NP = planes per operand: 3 = exact 3-way split (fp32-level accuracy, six partial products), 1 = plain bf16 operands
+// (round-to-nearest-even at staging, ONE product: the "bf16 GEMM inputs, fp32 accumulate" arithmetic of BASELINE configs[4]).
+template <int NP>
+struct SplitGeom {
+    static constexpr int OPER_B = NP * SP_PLANE_B;       // 12288 / 4096: the planes of one operand
+    static constexpr int STAGE_B = 2 * OPER_B;           // A planes, then B planes
+    // LDS of a workgroup that stages its epilogue in two 64-row halves (for_each_vec_halves below): the two bf16 stages (or
+    // the half-tile epilogue image, whichever is larger), then the iteration table -- 54,528 B (NP = 3: THREE workgroups fit
+    // a CU's 163,840 B, which the 166-VGPR kernels also allow) / 39,168 B (NP = 1).
+    static constexpr int EPI_HALF_B = 64 * G_LDS_KROW * 4;
+    static constexpr int TABLE_OFF_B = 2 * STAGE_B > EPI_HALF_B ? 2 * STAGE_B : EPI_HALF_B;
+    static constexpr int LDS_BYTES = TABLE_OFF_B + G_TABLE_BYTES;
+    static_assert(2 * STAGE_B <= 2 * G_STAGE * 4, "split stages fit the fp32 core's LDS footprint (table offset, epilogue image)");
+};
+constexpr int SP_LDS_BYTES = SplitGeom<3>::LDS_BYTES;
 // Byte offset of k-group g (8 k = 16 B) of row r inside a plane.  Rows are 32 B apart without padding; the k-group bit
 // is flipped for rows with bit 3 set, which makes both access patterns bank-conflict free (MI355X_MICROARCH.md, LDS):
 // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32) -- their 16 rows then fall
 // on 16 distinct 16-B bank quads; ds_write_b64 in 16 consecutive lanes = 4 rows x 4 k-quads = 32 distinct banks.
 __device__ __forceinline__ constexpr int sp_off(int r, int g) { return r * SP_ROW_B + ((g ^ ((r >> 3) & 1)) << 4); }
 
-template <bool REGION>
+template <bool REGION, int NP = 3>
 struct SplitCore : FastCore<true, REGION> {
     using Base = FastCore<true, REGION>;
+    using Geom = SplitGeom<NP>;
+    static constexpr int OPER_B = Geom::OPER_B, STAGE_B = Geom::STAGE_B;
     using Srds = typename Base::Srds;
     using Base::S;
     using Base::rm;
@@ -66,7 +75,7 @@ struct SplitCore : FastCore<true, REGION> {
     __device__ __forceinline__ SplitCore(const GemmSegs& s, RowMap r, int n0_, int N_, float* lds_, bool compact = false)
         : Base(s, r, n0_, N_, lds_) {
         // compact: the kernel allocated SP_LDS_BYTES only (table right behind the two bf16 stages, half-tile epilogue)
-        if (compact) table = reinterpret_cast<ItDesc*>(reinterpret_cast<char*>(lds) + SP_TABLE_OFF_B);
+        if (compact) table = reinterpret_cast<ItDesc*>(reinterpret_cast<char*>(lds) + Geom::TABLE_OFF_B);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rl = (tid >> 2) + 64 * j;
@@ -90,15 +99,16 @@ struct SplitCore : FastCore<true, REGION> {
         return Base::srd_load(d.b, ok ? 4u * (unsigned)(nl * d.ldb + k) : Base::SRD_OOB);
     }
 
-    // exact 3-way bf16 split of four consecutive-k values, written to the three planes (8 B each)
+    // exact NP-way bf16 split of four consecutive-k values (NP = 1: plain round-to-nearest-even), written to the NP
+    // planes (8 B each)
     __device__ __forceinline__ static void split_store(char* q, float4 v, int plane_stride = SP_PLANE_B) {
         f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const bf16x2 bl = __builtin_convertvector(lo, bf16x2), bh = __builtin_convertvector(hi, bf16x2);
             const unsigned ul = __builtin_bit_cast(unsigned, bl), uh = __builtin_bit_cast(unsigned, bh);
             *reinterpret_cast<uint2*>(q + p * plane_stride) = make_uint2(ul, uh);
-            if (p < 2) {
+            if (p < NP - 1) {
                 const f32x2 fl = {__uint_as_float(ul << 16), __uint_as_float(ul & 0xffff0000u)};
                 const f32x2 fh = {__uint_as_float(uh << 16), __uint_as_float(uh & 0xffff0000u)};
                 lo -= fl;
@@ -109,14 +119,14 @@ struct SplitCore : FastCore<true, REGION> {
     // store the thread's slots of half h (slots h and h+2) of one register set
     template <bool RELU>
     __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4]) const {
-        char* st = reinterpret_cast<char*>(lds) + h * SP_STAGE_B;
+        char* st = reinterpret_cast<char*>(lds) + h * STAGE_B;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float4 a = ra[h + 2 * j];
             if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             const int off = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
             split_store(st + off, a);
-            split_store(st + SP_OPER_B + off, rb[h + 2 * j]);
+            split_store(st + OPER_B + off, rb[h + 2 * j]);
         }
     }
     // (re)load the thread's slots of half h (slots h and h+2) from slab `t`; `live` = false requests nothing (offsets
@@ -130,26 +140,28 @@ struct SplitCore : FastCore<true, REGION> {
 #pragma unroll
         for (int j = 0; j < 2; ++j) { ra[h + 2 * j] = sload_a(d, h + 2 * j); rb[h + 2 * j] = sload_b(d, h + 2 * j); }
     }
-    // fragments of half h: three planes of two 32-row blocks per operand (12 x ds_read_b128)
-    struct Frags { bf16x8 a[2][3], b[2][3]; };
+    // fragments of half h: NP planes of two 32-row blocks per operand (4 NP x ds_read_b128)
+    struct Frags { bf16x8 a[2][NP], b[2][NP]; };
     __device__ __forceinline__ Frags read_frags(int h) const {
-        const char* st = reinterpret_cast<const char*>(lds) + h * SP_STAGE_B;
+        const char* st = reinterpret_cast<const char*>(lds) + h * STAGE_B;
         const int lr = lane & 31, lh = lane >> 5;
         Frags f;
 #pragma unroll
-        for (int p = 2; p >= 0; --p)             // plane 2 of A and plane 0 of B feed the first MFMAs
+        for (int p = NP - 1; p >= 0; --p)        // the last plane of A and plane 0 of B feed the first MFMAs
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f.a[t][p] = *reinterpret_cast<const bf16x8*>(st + p * SP_PLANE_B + sp_off(wr * 64 + t * 32 + lr, lh));
-                f.b[t][2 - p] = *reinterpret_cast<const bf16x8*>(st + SP_OPER_B + (2 - p) * SP_PLANE_B + sp_off(wc * 64 + t * 32 + lr, lh));
+                f.b[t][NP - 1 - p] = *reinterpret_cast<const bf16x8*>(st + OPER_B + (NP - 1 - p) * SP_PLANE_B + sp_off(wc * 64 + t * 32 + lr, lh));
             }
         return f;
     }
-    // acc += A_h x B_h^T over 16 k: 24 MFMAs (6 partial products x 4 tiles, the four accumulators round-robin)
+    // acc += A_h x B_h^T over 16 k: NP = 3: 24 MFMAs (6 partial products x 4 tiles, the four accumulators round-robin);
+    // NP = 1: 4 MFMAs
+    static constexpr int NPROD = NP == 3 ? 6 : 1;
     __device__ __forceinline__ static void mfmas(const Frags& f, f32x16 (&acc)[2][2]) {
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+        constexpr int PA[6] = {NP == 3 ? 2 : 0, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < NPROD; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -171,13 +183,24 @@ struct SplitCore : FastCore<true, REGION> {
         store_half<RELU>(hs, ra, rb);
         mfmas(f, acc);
         load_half(hs, next, ra, rb);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // all fragment reads
+        if (NP == 3) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // all fragment reads
 #pragma unroll
-        for (int r = 0; r < 24; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (split arithmetic)
-            if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
-            if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            for (int r = 0; r < 24; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (split arithmetic)
+                if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
+                if (r >= 18 && r < 22) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);       // the four fragment reads
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (conversion)
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }

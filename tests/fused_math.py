@@ -48,23 +48,33 @@ def compose(p, num_regions, regional=True, prefix="tgnn."):
     return out
 
 
-def forward_fused(p, x, a_hat, l_list, regional=True):
-    """x (N,F,T).  Returns (pred, hidden) through the composed-weight formulation using autograd."""
+def bf16_round(t):
+    """Round-to-nearest-even to bf16 and back: what REGT_GEMM_MODE=bf16 does to every operand of a big GEMM."""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None):
+    """x (N,F,T).  Returns (pred, hidden) through the composed-weight formulation using autograd.
+
+    ``rnd``: optional rounding applied to both operands of every activation x weight contraction that the HIP path
+    runs on the matrix cores (``bf16_round`` emulates REGT_GEMM_MODE=bf16; accumulation, SpMM, compositions, gate
+    math and the skinny last head layer stay fp32, as in the kernels)."""
+    q = (lambda v: v) if rnd is None else rnd
     n, f, t = x.shape
     R = len(l_list)
     w = compose(p, R, regional)
     xp = x.permute(0, 2, 1)                              # (N,T,F) packed rows
     ax = torch.einsum("ij,jtf->itf", a_hat, xp)
-    pre = xp @ w["A0"].t() + w["b"]
+    pre = q(xp) @ q(w["A0"]).t() + w["b"]
     for r in range(R):
-        pre = pre + torch.einsum("ij,jtf->itf", l_list[r], xp) @ w["Ar"][r].t()
+        pre = pre + q(torch.einsum("ij,jtf->itf", l_list[r], xp)) @ q(w["Ar"][r]).t()
     h = torch.nn.functional.leaky_relu(pre, LRELU) if regional else pre
-    z = torch.sigmoid(h @ w["Uz"].t() + ax @ w["Gz"].t() + w["cz"])
-    r_ = torch.sigmoid(h @ w["Ur"].t() + ax @ w["Gr"].t() + w["cr"])
-    ht = torch.tanh((h * r_) @ w["Uh"].t() + ax @ w["Gh"].t() + w["ch"])
+    z = torch.sigmoid(q(h) @ q(w["Uz"]).t() + q(ax) @ q(w["Gz"]).t() + w["cz"])
+    r_ = torch.sigmoid(q(h) @ q(w["Ur"]).t() + q(ax) @ q(w["Gr"]).t() + w["cr"])
+    ht = torch.tanh(q(h * r_) @ q(w["Uh"]).t() + q(ax) @ q(w["Gh"]).t() + w["ch"])
     hn = z * h + (1 - z) * ht
     probs = torch.softmax(p["tgnn._attention"], dim=0)
     hidden = (hn * probs.view(1, t, 1)).sum(dim=1)
-    y = torch.relu(hidden) @ p["linear1.weight"].t() + p["linear1.bias"]
+    y = q(torch.relu(hidden)) @ q(p["linear1.weight"]).t() + p["linear1.bias"]
     y = torch.relu(y) @ p["linear2.weight"].t() + p["linear2.bias"]
     return y, hidden

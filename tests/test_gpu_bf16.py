@@ -1,0 +1,156 @@
+"""Reduced-precision GEMM mode of BASELINE configs[4] (REGT_GEMM_MODE=bf16 / regt_set_gemm_mode(2)): activations and
+weights are rounded to bf16 (round-to-nearest-even) while they are staged into LDS, v_mfma_f32_32x32x16_bf16 accumulates in
+fp32; SpMM, weight compositions, gate math, reductions and the skinny (C x F) gradients stay fp32.
+
+The reference has no bf16 path, so the tolerance is derived, not inherited:
+  * bf16 keeps 8 significant bits: unit roundoff u = 2^-9.  One product of two rounded operands carries a relative error
+    <= 2u + u^2; a K-term contraction with fp32 accumulation is off by at most 2u * sum|a_k b_k| and, for the mixed-sign
+    operands here, by about 2u * sqrt(sum (a_k b_k)^2).  Sigmoid / tanh / the convex GRU blend do not amplify it.
+  * Emulating exactly this rounding on the CPU (tests/fused_math.py, ``rnd=bf16_round``) against the fp32 oracle gives
+    max|d hidden| = 1.0e-3 .. 3.2e-3 at max|hidden| = 0.41 .. 1.62, i.e. 1.0 .. 1.3 u of the tensor's scale.
+  TOL_REL = 8 u = 1.5625e-2 of the reference tensor's max magnitude (outputs) / Frobenius norm (gradients) is the stated bar.
+A second, tight bar pins the arithmetic itself: the HIP result must agree with the CPU emulation of the same rounding to
+EMU_TOL = 3e-4 of the tensor's scale (what is left are fp32 summation order and operands that sit on a bf16 rounding boundary).
+"""
+import numpy as np
+import pytest
+import torch
+
+from fused_math import bf16_round, dense_ops, forward_fused
+from oracle import model as M
+from test_gpu_model import _synthetic
+
+pytestmark = pytest.mark.gpu
+BF16_U = 2.0 ** -9
+TOL_REL = 8 * BF16_U
+EMU_TOL = 3e-4
+
+
+@pytest.fixture()
+def bf16_mode():
+    import regtgcn_amd as R
+    lib = R.load_library()
+    prev = lib.regt_set_gemm_mode(2)
+    assert lib.regt_set_gemm_mode(2) == 2
+    yield R
+    lib.regt_set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("m,k,n,act", [(4096, 320, 512, 0), (1000, 100, 36, 1), (130, 2048, 256, 2), (7, 4, 4, 0)])
+def test_bf16_linear_is_the_rounded_operand_product(bf16_mode, m, k, n, act):
+    R = bf16_mode
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / max(1.0, k ** 0.5)
+    b = torch.randn(n, generator=g)
+
+    def ref(aa, ww):
+        v = aa.double() @ ww.double().t() + b.double()
+        return torch.nn.functional.leaky_relu(v, 0.01) if act == 1 else (torch.relu(v) if act == 2 else v)
+
+    got = R.ops.linear(a.cuda(), w.cuda(), b.cuda(), act).cpu().double()
+    # exactly the product of the bf16-rounded operands, accumulated in fp32
+    assert float((got - ref(bf16_round(a), bf16_round(w))).abs().max()) < 2e-5
+    # and within the derived bound of the unrounded product: 2u * sum|a_k w_k|
+    bound = 2.2 * BF16_U * (a.abs().double() @ w.abs().double().t()) + 1e-6
+    assert bool(((got - ref(a, w)).abs() <= bound).all())
+
+
+@pytest.mark.parametrize("m,n,k", [(5000, 256, 256), (3001, 512, 256), (2048, 256, 64)])
+def test_bf16_wgrad_is_the_rounded_operand_product(bf16_mode, m, n, k):
+    R = bf16_mode
+    g = torch.Generator().manual_seed(m)
+    d = torch.randn(m, n, generator=g)
+    a = torch.randn(m, k, generator=g)
+    dw, db = R.ops.wgrad(d.cuda(), a.cuda())
+    want = bf16_round(d).double().t() @ bf16_round(a).double()
+    scale = float(want.abs().max())
+    assert float((dw.cpu().double() - want).abs().max()) < 1e-5 * scale + 1e-4
+    np.testing.assert_allclose(db.cpu().numpy(), d.sum(0).numpy(), rtol=1e-4, atol=1e-3)      # bias gradient stays fp32
+
+
+# (nodes, edges, regions, F, T, O): F = 64 and 64 regions are the BASELINE configs[4] shapes; the first row is a cfg-3 shape
+SHAPES = [(1500, 15000, 8, 32, 12, 1), (2048, 20000, 64, 64, 12, 1), (1200, 9000, 4, 64, 12, 3)]
+
+
+def _models(R, n, e, regions, f, t, o):
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
+    mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+    mod.load_state_dict(p, strict=True)
+    return ei, ri, rw, x, y, p, mod.cuda()
+
+
+@pytest.mark.parametrize("n,e,regions,f,t,o", SHAPES)
+def test_bf16_mode_matches_oracle_within_derived_tolerance(bf16_mode, n, e, regions, f, t, o):
+    R = bf16_mode
+    ei, ri, rw, x, y, p, mod = _models(R, n, e, regions, f, t, o)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    pred_o, hid_o = M.regional_temporal_gcn(po, x, ei, ri, rw)
+    torch.mean((pred_o - y) ** 2).backward()
+    pred, hidden = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    torch.mean((pred - y.cuda()) ** 2).backward()
+    for got, want in ((pred, pred_o), (hidden, hid_o)):
+        assert float((got.detach().cpu() - want.detach()).abs().max()) <= TOL_REL * float(want.detach().abs().max())
+    for k, q in mod.named_parameters():
+        if k in M.UNUSED_PARAMS:
+            continue
+        want = po[k].grad
+        err = float((q.grad.cpu() - want).norm())
+        # softmax backward subtracts the probability-weighted mean of dL/dp (the T attention gradients sum to 0): the result
+        # is a difference of nearly equal terms, so its relative error is a multiple of theirs -- 4x the bar for this tensor
+        tol = TOL_REL * (4.0 if k == "tgnn._attention" else 1.0)
+        assert err <= tol * float(want.norm()) + 1e-9, (k, err, float(want.norm()))
+
+
+@pytest.mark.parametrize("n,e,regions,f,t,o", SHAPES[:2])
+def test_bf16_mode_is_exactly_operand_rounding(bf16_mode, n, e, regions, f, t, o):
+    """Forward against the CPU emulation that rounds the same operands: nothing else differs from the fp32 pipeline."""
+    R = bf16_mode
+    ei, ri, rw, x, y, p, mod = _models(R, n, e, regions, f, t, o)
+    a, ls = dense_ops(ei, None, ri, rw, n, torch.float32)
+    with torch.no_grad():
+        pred_e, hid_e = forward_fused(p, x, a, ls, regional=True, rnd=bf16_round)
+        pred_f, hid_f = forward_fused(p, x, a, ls, regional=True)
+        pred, hidden = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a_.cuda() for a_ in rw])
+    report = []
+    for name, got, emu, full in (("pred", pred, pred_e, pred_f), ("hidden", hidden, hid_e, hid_f)):
+        scale = float(emu.abs().max())
+        report.append((name, float((got.cpu() - emu).abs().max()) / scale, float((got.cpu() - full).abs().max()) / scale))
+    print("bf16 emulation check (tensor, |hip - emu| / scale, |hip - fp32| / scale):", report)
+    # hidden: the cell output itself.  (pred is a small difference of large head terms, and the composed (C,F) weights are
+    # formed in another fp32 summation order on the GPU: a weight that lands on a bf16 rounding boundary flips for ALL rows
+    # at once, which moves pred by as much as the rounding itself -- it is held to the derived tolerance above instead.)
+    name, d_emu, d_full = report[1]
+    assert d_emu <= EMU_TOL, report
+    # the mode is really reduced precision (guards against silently running the fp32 kernels)
+    assert d_full > 2 * EMU_TOL, report
+
+
+def test_bf16_mode_trains(bf16_mode):
+    """A few RMSprop steps in bf16 mode reduce the loss like the fp32 pipeline does (same data, same init)."""
+    R = bf16_mode
+    lib = R.load_library()
+    n, e, regions, f, t, o = 1500, 15000, 8, 32, 12, 1
+    losses = {}
+    for mode in (0, 2):
+        lib.regt_set_gemm_mode(mode)
+        ei, ri, rw, x, y, p, mod = _models(R, n, e, regions, f, t, o)
+        opt = torch.optim.RMSprop(mod.parameters(), lr=1e-3, weight_decay=1e-4)
+        graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        xs, ys, seq = x.cuda(), y.cuda(), []
+        for _ in range(6):
+            pred, _h = mod.forward_prepared(xs, graph)
+            loss = torch.mean((pred - ys) ** 2)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            seq.append(float(loss.detach()))
+        losses[mode] = seq
+    lib.regt_set_gemm_mode(2)
+    assert losses[2][-1] < losses[2][0]
+    # RMSprop divides by the gradient's running RMS, so later steps amplify small gradient differences: hold the first two
+    # steps (same parameters / one update apart) to 2 % and the rest to the same order of magnitude
+    np.testing.assert_allclose(losses[2][:2], losses[0][:2], rtol=0.02)
+    np.testing.assert_allclose(losses[2], losses[0], rtol=0.5)
