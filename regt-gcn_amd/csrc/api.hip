@@ -92,9 +92,13 @@ static bool graphs_wanted(long rows) {
 }
 
 // Runs `enqueue(stream)` either eagerly on `st` or as a cached graph replay ordered after / before `st`.
+static std::mutex g_graph_stream_mu;   // g_graph_stream / g_ev_in / g_ev_out are shared by the forward and backward caches
 static int run_maybe_graphed(GraphCache& cache, unsigned long long key, hipStream_t st,
                              const std::function<int(hipStream_t)>& enqueue) {
+    std::lock_guard<std::mutex> lk_stream(g_graph_stream_mu);
     std::lock_guard<std::mutex> lk(cache.mu);
+    const int gm = gemm_mode();            // a captured launch sequence is only valid for the arithmetic it was captured with
+    key = hash_bytes(&gm, sizeof(gm), key);
     GraphEntry& e = cache.map[key];
     if (!e.exec) {
         if (e.seen++ == 0 || cache.map.size() > 256) {   // first sighting (also sets kernel attributes), or buffers
@@ -262,6 +266,7 @@ SgTerm term(const float* A, long sai, long sak, long sab, const float* B, long s
 }
 void add_task(SgBatch& b, float* C, long sci, long scj, long scb, int m, int n, int nbatch, const float* init, long init_si,
               std::initializer_list<SgTerm> terms, long init_sj = 0) {
+    if (b.ntask >= SG_MAX_TASKS) { b.overflow = 1; return; }
     SgTask& t = b.task[b.ntask++];
     t = SgTask{};
     t.C = C; t.sci = sci; t.scj = scj; t.scb = scb; t.m = m; t.n = n; t.nbatch = nbatch; t.init = init; t.init_si = init_si;

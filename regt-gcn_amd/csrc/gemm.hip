@@ -1237,7 +1237,8 @@ __global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
 }
 
 int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
-    REGT_CHECK_ARG(b.ntask > 0 && b.ntask <= SG_MAX_TASKS, "small_gemm_multi: %d tasks", b.ntask);
+    REGT_CHECK_ARG(b.ntask > 0 && b.ntask <= SG_MAX_TASKS && !b.overflow, "small_gemm_multi: %d tasks%s", b.ntask,
+                   b.overflow ? " (more than SG_MAX_TASKS were added)" : "");
     int blocks = 0;
     for (int t = 0; t < b.ntask; ++t) {
         b.block_start[t] = blocks;

@@ -116,9 +116,10 @@ struct SgTask {
     SgTerm term[3];
     int split;                   // lanes per output element (set by launch_small_gemm_multi: 1 for short sums, 8 for long ones)
 };
-constexpr int SG_MAX_TASKS = 10;
+constexpr int SG_MAX_TASKS = 12;
 struct SgBatch {
     int ntask;
+    int overflow;                // set by add_task when a task did not fit (launch_small_gemm_multi then fails)
     int block_start[SG_MAX_TASKS + 1];
     SgTask task[SG_MAX_TASKS];
 };

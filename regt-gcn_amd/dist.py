@@ -214,6 +214,9 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     val_a = val[b:e].contiguous()
     # regional Laplacians of the owned regions, in local ids
     mine = [r for r in range(len(region_index)) if region_owner[r] == rank]
+    if not mine:
+        raise ValueError(f"rank {rank} owns no region: a region shard needs at least one region per rank "
+                         f"({len(region_index)} regions over {world} ranks)")
     loc_idx = [(region_index[r] - lo).to(device) for r in mine]
     loc_w = [region_attr[r].to(device) for r in mine]
     n_loc = hi - lo

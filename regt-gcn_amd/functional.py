@@ -235,8 +235,10 @@ class FusedTrainStep:
         self.acc = torch.zeros(total + sum(pad), dtype=torch.float32, device=dev)
         self.step_grad = torch.empty_like(self.acc)
         views, off = {}, 0
+        self._acc_views = []
         for n_, p_, extra in zip(names, self.params, pad):
             p_.grad = self.acc[off:off + p_.numel()].view_as(p_)
+            self._acc_views.append(p_.grad)
             views[n_] = self.step_grad[off:off + p_.numel()].view_as(p_)
             off += p_.numel() + extra
         self.ps = _fill(_lib.Params(), tens, self.regional)
@@ -256,6 +258,15 @@ class FusedTrainStep:
             raise ValueError(f"x must be a contiguous float32 CUDA tensor of shape {self.shape_x}")
         if tuple(y.shape) != tuple(self.pred.shape) or y.dtype != torch.float32 or not y.is_contiguous():
             raise ValueError(f"y must be a contiguous float32 tensor of shape {tuple(self.pred.shape)}")
+        for p_, view in zip(self.params, self._acc_views):
+            if p_.grad is not view:
+                # optimizer.zero_grad() with its default set_to_none=True dropped the views: the optimiser would skip every
+                # parameter while this object kept accumulating into a detached buffer.  Re-attach (cleared, as requested).
+                if p_.grad is None:
+                    view.zero_()
+                else:
+                    view.copy_(p_.grad)
+                p_.grad = view
         _lib.check(lib.regt_forward(C.byref(self.dims), C.byref(self.gs), C.byref(self.ps), _lib.ptr(x), _lib.ptr(self.pred),
                                     _lib.ptr(self.hidden), _lib.ptr(self.ws), self.wsb, st), "regt_forward")
         cnt = self.pred.numel()

@@ -77,10 +77,17 @@ class TGCN(nn.Module):
 
 
 class _GraphCache:
-    """Prepared graphs keyed first by tensor identity (free), then by content fingerprint (one 8-byte readback)."""
+    """Prepared graphs keyed first by tensor identity (free), then by content fingerprint (one 8-byte readback).
+
+    An identity entry keeps strong references to its key tensors: while the entry lives their storage cannot be freed and
+    handed to a new tensor with other edges at the same address, so (data_ptr, shape, _version) really identifies the
+    content (an in-place edit bumps ``_version``).  The identity table is small (a loader that builds a fresh ``edge_index``
+    per snapshot, run.py:172, goes through the fingerprint every time) so that it pins at most a few edge lists."""
+
+    MAX_IDENT = 8
 
     def __init__(self):
-        self._by_id: Dict[tuple, PreparedGraph] = {}
+        self._by_id: Dict[tuple, tuple] = {}            # key -> (graph, key tensors)
         self._by_hash: Dict[tuple, PreparedGraph] = {}
 
     @staticmethod
@@ -89,17 +96,17 @@ class _GraphCache:
 
     def get(self, tensors: Sequence[Optional[torch.Tensor]], num_nodes: int, build):
         key = (num_nodes,) + self._ident(tensors)
-        g = self._by_id.get(key)
-        if g is not None:
-            return g
+        hit = self._by_id.get(key)
+        if hit is not None and all(a is b for a, b in zip(hit[1], tensors)):
+            return hit[0]
         hkey = (num_nodes, fingerprint(tensors))
         g = self._by_hash.get(hkey)
         if g is None:
             g = build()
             self._by_hash[hkey] = g
-        if len(self._by_id) > 64:
+        if len(self._by_id) >= self.MAX_IDENT:
             self._by_id.clear()
-        self._by_id[key] = g
+        self._by_id[key] = (g, tuple(tensors))
         return g
 
 

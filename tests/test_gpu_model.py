@@ -22,6 +22,17 @@ def R():
     return regtgcn_amd
 
 
+@pytest.fixture(params=[0, 1], ids=["fp32mfma", "bf16x3split"])
+def arith(request, R):
+    """GEMM arithmetic for the parity tests that take this fixture: the default fp32 MFMA and the opt-in exact 3-way bf16
+    split (regt_set_gemm_mode(1)) are held to the SAME goldens, oracle and 1e-5 -- so the driver's GPU run itself shows that
+    the split "passes the same parity suite" (DESIGN.md 5a)."""
+    lib = R.load_library()
+    prev = lib.regt_set_gemm_mode(request.param)
+    yield request.param
+    lib.regt_set_gemm_mode(prev)
+
+
 def _cuda_list(ts):
     return [t.cuda() for t in ts]
 
@@ -40,7 +51,7 @@ def _run_regt(R, params, x, y, fx, num_regions=5):
 
 
 @pytest.mark.parametrize("tag", ["in6_out1", "in12_out1", "in12_out3", "in6_out3", "ckpt"])
-def test_regt_matches_reference_goldens(R, tpims, tag):
+def test_regt_matches_reference_goldens(R, arith, tpims, tag):
     g = load_npz(f"golden_regt_{tag}.npz")
     t_in, t_out, w0 = int(g["t_in"]), int(g["t_out"]), int(g["window"])
     n = tpims["node_data"].shape[0]
@@ -60,7 +71,7 @@ def test_regt_matches_reference_goldens(R, tpims, tag):
 
 
 @pytest.mark.parametrize("tag", ["in6_out1", "in12_out3"])
-def test_temporal_gcn_matches_reference_goldens(R, tpims, tag):
+def test_temporal_gcn_matches_reference_goldens(R, arith, tpims, tag):
     g = load_npz(f"golden_tgcn_{tag}.npz")
     t_in, t_out, w0 = int(g["t_in"]), int(g["t_out"]), int(g["window"])
     p = M.init_params("TemporalGCN", 8, t_in, t_out, seed=int(g["seed"]))
@@ -111,7 +122,7 @@ def _synthetic(n, e, regions, f, t, seed):
                                               (2000, 16000, 64, 8, 6, 1),      # 64 regions = the 8-GPU global region count
                                               (1200, 9000, 4, 64, 12, 1),      # feat_dim 64 (BASELINE configs[4])
                                               (2048, 20000, 64, 64, 12, 1)])   # feat_dim 64 AND 64 regions: the configs[4] shapes at fp32 1e-5
-def test_regt_matches_oracle_on_synthetic_regional_graph(R, n, e, regions, f, t, o):
+def test_regt_matches_oracle_on_synthetic_regional_graph(R, arith, n, e, regions, f, t, o):
     ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n)
     y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
     p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
@@ -136,7 +147,7 @@ def test_regt_matches_oracle_on_synthetic_regional_graph(R, n, e, regions, f, t,
 
 
 @pytest.mark.parametrize("n,e,regions,f,t,o", [(900, 6000, 5, 8, 6, 1), (3000, 30000, 3, 32, 12, 2)])
-def test_overlapping_random_decomposition_matches_oracle(R, n, e, regions, f, t, o):
+def test_overlapping_random_decomposition_matches_oracle(R, arith, n, e, regions, f, t, o):
     """The reference's 'random' decomposition (load_dataset.py:324-329): the edges of the full graph are dealt
     to R regional graphs at random, so every node has edges in several of them (general, non-disjoint mode)."""
     g = torch.Generator().manual_seed(n)
@@ -207,10 +218,11 @@ def test_hidden_gradient_path(R, tpims):
 
 
 def test_region_sharded_path_matches_single_gpu(R):
-    """Two region shards executed one after the other on the one GPU (halo rows copied by hand instead of
-    exchanged): predictions, hidden rows and the summed gradients equal the unsharded run."""
+    """Three region shards executed one after the other on the one GPU (halo rows copied by hand instead of
+    exchanged): predictions, hidden rows and the summed gradients equal the unsharded run.  The middle rank owns a region
+    block with region_lo > 0 and region_hi < R (all three gradient-composition tasks of tgnn.linear.weight)."""
     import numpy as np
-    world, n_per, regions_per, f, t, o = 2, 1500, 3, 8, 6, 2
+    world, n_per, regions_per, f, t, o = 3, 1000, 3, 8, 6, 2
     n = n_per * world
     g = R.data.synthetic_regional_graph(n, 12000 * world, regions_per * world, seed=5, p_intra=0.85)
     (x, y), = R.data.synthetic_snapshots(n, f, t, o, 1, seed=5)
@@ -245,7 +257,7 @@ def test_region_sharded_path_matches_single_gpu(R):
         np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.cpu().numpy(), atol=2e-6, rtol=1e-4, err_msg=k)
 
 
-def test_training_loop_matches_reference_trajectory(R, tpims):
+def test_training_loop_matches_reference_trajectory(R, arith, tpims):
     """run.py semantics (accumulate over snapshots, one RMSprop step per epoch, (rmse, mse) test) driven through the
     HIP module reproduce the trajectory recorded from the reference's own module (golden_loop.npz)."""
     g = load_npz("golden_loop.npz")
