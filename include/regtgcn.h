@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 3
+#define REGT_ABI_VERSION 4
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -59,6 +59,12 @@ int32_t regt_raw_csr(const int64_t* edge_index, const float* edge_value, int64_t
                      int32_t* rowptr, int32_t* col, float* val, int32_t* flags_dev,
                      void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* Mean-aggregation operator of SAGEConv(aggr='mean') (base block 'graphsage' of the TGCN cell, models/utils.py:99-100): row i
+ * holds every listed in-edge j -> i (self loops and duplicate edges as listed) with weight 1 / in-degree(i); rowptr (N+1),
+ * col/val (E).  Nodes without in-edges get an empty row (their mean is 0, as in PyG). */
+int32_t regt_mean_csr(const int64_t* edge_index, int64_t num_edges, int32_t num_nodes, int32_t* rowptr, int32_t* col,
+                      float* val, int32_t* flags_dev, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
 /* Order-independent 64-bit fingerprint of (edge_index, edge_weight) -- cache key for prepared graphs. */
 int32_t regt_graph_fingerprint(const int64_t* edge_index, const float* edge_weight, int64_t num_edges,
                                uint64_t* out_dev, regt_stream_t stream);
@@ -82,6 +88,7 @@ int32_t regt_pack_x(const float* x, float* x_packed, int32_t num_nodes, int32_t 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction -- torch.nn.Linear / PyG Linear call sites:
  *   out[M,N] = act(A[M,K] W[N,K]^T + bias)     act: 0 none, 1 leaky_relu(slope), 2 relu
+ *                                              (3 sigmoid, 4 tanh: gate epilogues of the zero-hidden cell)
  * and the matching weight gradient  dW[N,K] = dOut[M,N]^T A[M,K]  (+ optional dbias = column sums).
  * regt_wgrad needs `slab` of regt_wgrad_slab_floats(...) floats.
  * ---------------------------------------------------------------------------------------------- */
@@ -206,6 +213,53 @@ int32_t regt_cell_forward(const regt_dims* dims, const regt_graph* graph, const 
 int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
                            const regt_grads* grads, const float* dpred, const float* dhidden, const float* hidden,
                            const float* h_in, float* dh_in, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Zero-hidden TGCN cell + attention over periods + head, on gate inputs the CALLER aggregated.
+ *
+ * The reference's GraphSAGETemporalGCN and GATTemporal call `self._base_tgcn(X[:, :, period], edge_index, H)`
+ * (models/GraphSAGETemporalGCN.py:93-95, models/GATTemporal.py:78-80): the third positional parameter of TGCN.forward is
+ * edge_weight, so H stays None and the cell starts from zeros (models/utils.py:163-166).  With H = 0 the GRU reduces to
+ *     Z = sigmoid(a_z gz^T + cz),   H~ = tanh(a_h gh^T + ch),   H' = (1 - Z) * H~,   hidden = sum_t softmax(att)_t H'_t
+ * (the reset gate only ever multiplies H = 0).  a_z (M, kz) / a_h (M, kh), M = N*T rows ordered node*T + t, are the
+ * aggregated inputs of the two live gates -- [mean-neighbour x | x] for SAGEConv, the attention-weighted neighbour sum of
+ * GATConv (regt_gat_forward) -- and gz (C, kz) / gh (C, kh), cz / ch (C) the composed weights U_k[:, :C] W_k and biases
+ * U_k[:, :C] b_k + u_k.  dims: N, T, C, O, H1 are used.  regt_cell0_backward writes the gradients of args' tensors; the
+ * optional a_z / a_h entries (M, kz) / (M, kh) receive dL/d(input) (needed when the inputs depend on parameters: GAT).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct regt_cell0_args {
+    const float* a_z; const float* a_h;
+    int32_t kz, kh;
+    const float* gz; const float* gh; const float* cz; const float* ch;
+    const float* attention;                                          /* (T) */
+    const float* head1_w; const float* head1_b; const float* head2_w; const float* head2_b;
+} regt_cell0_args;
+typedef struct regt_cell0_grads {
+    float* a_z; float* a_h;                                          /* optional (NULL = not needed) */
+    float* gz; float* gh; float* cz; float* ch;
+    float* attention;                                                /* optional */
+    float* head1_w; float* head1_b; float* head2_w; float* head2_b;
+} regt_cell0_grads;
+size_t regt_cell0_workspace_bytes(const regt_dims* dims, int32_t kz, int32_t kh);
+int32_t regt_cell0_forward(const regt_dims* dims, const regt_cell0_args* args, float* pred, float* hidden, void* workspace,
+                           size_t workspace_bytes, regt_stream_t stream);
+int32_t regt_cell0_backward(const regt_dims* dims, const regt_cell0_args* args, const regt_cell0_grads* grads, const float* dpred,
+                            const float* dhidden, const float* hidden, void* workspace, size_t workspace_bytes,
+                            regt_stream_t stream);
+
+/* GATConv (heads = 1, add_self_loops, negative_slope `slope`) attention aggregation on the INPUT rows, all T periods at once:
+ *   e_ij = leaky_relu(<x_j, u_src> + <x_i, u_dst>),  alpha_ij = softmax over the in-edges of i,  out_i = sum_j alpha_ij x_j
+ * with u_src = W^T att_src, u_dst = W^T att_dst (F) -- the conv's output is then out W^T + bias (models/utils.py:97-98 call
+ * sites).  rowptr/col: the pattern of regt_gcn_csr (in-edges without self loops + one self loop per node).  x, out:
+ * (N, T, F) packed rows; stats (N*T, 4) floats are kept for the backward.  regt_gat_backward turns dL/dout (N, T, F) into
+ * the score gradients dsd (N*T, 2) = (dL/ds_j, dL/dd_i) per row; du_src = dsd[:, 0]^T x and du_dst = dsd[:, 1]^T x are then
+ * ordinary regt_wgrad contractions.  t_rowptr/t_col: the transposed pattern (out-edges of every node). */
+int32_t regt_gat_forward(const int32_t* rowptr, const int32_t* col, const float* x, const float* u_src, const float* u_dst,
+                         float slope, int32_t num_nodes, int32_t periods, int32_t num_features, float* out, float* stats,
+                         regt_stream_t stream);
+int32_t regt_gat_backward(const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col,
+                          const float* x, const float* u_src, float slope, int32_t num_nodes, int32_t periods,
+                          int32_t num_features, const float* dout, float* stats, float* dsd, regt_stream_t stream);
 
 /* Arithmetic of the dense contractions.  0 (default): fp32 MFMA (v_mfma_f32_32x32x2_f32).  1: every fp32 operand is
  * split exactly into three bf16 pieces and the six leading partial products run on the bf16 MFMA with fp32

@@ -19,7 +19,7 @@ import torch
 
 __all__ = [
     "gcn_norm_edges", "cheb_norm_edges", "propagate", "gcn_conv", "cheb_conv",
-    "dense_gcn_operator", "dense_cheb_operator",
+    "dense_gcn_operator", "dense_cheb_operator", "sage_conv", "gat_conv", "dense_mean_operator", "dense_gat_attention",
 ]
 
 
@@ -105,7 +105,70 @@ def cheb_conv(x, edge_index, edge_weight, w0, w1, bias):
     return x @ w0.t() + tx1 @ w1.t() + bias
 
 
+def sage_conv(x, edge_index, lin_l_weight, lin_l_bias, lin_r_weight):
+    """PyG ``SAGEConv(aggr='mean', root_weight=True, normalize=False, project=False)`` -- base block 'graphsage' of the
+    reference's TGCN cell (models/utils.py:99-100; called as ``conv(X, edge_index, None)``, the third positional being
+    SAGEConv's ``size``).  ``out_i = lin_l(mean_{j -> i} x_j) + lin_r(x_i)``: the mean runs over every listed in-edge (self
+    loops and duplicates as listed; ``scatter(..., reduce='mean')`` = sum / max(count, 1), so isolated targets get 0);
+    ``lin_l`` carries the bias, ``lin_r`` has none."""
+    n = x.shape[0]
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    s = torch.zeros(n, x.shape[1], dtype=x.dtype).index_add_(0, dst, x.index_select(0, src))
+    cnt = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(src.numel(), dtype=x.dtype))
+    mean = s / cnt.clamp(min=1).view(-1, 1)
+    return mean @ lin_l_weight.t() + lin_l_bias + x @ lin_r_weight.t()
+
+
+def gat_conv(x, edge_index, lin_weight, att_src, att_dst, bias, negative_slope: float = 0.2):
+    """PyG ``GATConv(heads=1, concat=True, negative_slope=0.2, dropout=0, add_self_loops=True, edge_dim=None, bias=True)`` --
+    base block 'gat' of the reference's TGCN cell (models/utils.py:97-98; called as ``conv(X, edge_index, None)``, the third
+    positional being GATConv's ``edge_attr``).
+
+    ``x' = x W^T``; ``a_s = <x', att_src>``, ``a_d = <x', att_dst>`` per node; self loops are removed and one loop per node is
+    added; ``e_ij = leaky_relu(a_s[j] + a_d[i])`` for every edge j -> i; ``alpha = softmax`` over the in-edges of i
+    (``exp(e - max) / (sum + 1e-16)``, torch_geometric.utils.softmax); ``out_i = sum_j alpha_ij x'_j + bias``."""
+    n = x.shape[0]
+    xs = x @ lin_weight.t()
+    a_s = (xs * att_src.reshape(1, -1)).sum(-1)
+    a_d = (xs * att_dst.reshape(1, -1)).sum(-1)
+    src, dst = edge_index[0].long(), edge_index[1].long()
+    keep = src != dst
+    ar = torch.arange(n, dtype=torch.long)
+    src, dst = torch.cat([src[keep], ar]), torch.cat([dst[keep], ar])
+    e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], negative_slope)
+    emax = torch.full((n,), float("-inf"), dtype=x.dtype).scatter_reduce(0, dst, e.detach(), "amax", include_self=True)
+    ex = (e - emax[dst]).exp()
+    den = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, ex) + 1e-16
+    alpha = ex / den[dst]
+    out = torch.zeros(n, xs.shape[1], dtype=x.dtype).index_add_(0, dst, alpha.view(-1, 1) * xs.index_select(0, src))
+    return out + bias
+
+
 # ---- dense-matrix statements of the same operators (used for known-answer tests) --------------
+
+def dense_mean_operator(edge_index, num_nodes, dtype=torch.float64):
+    """Row-normalised in-adjacency: ``A[i, j]`` = (number of listed edges j -> i) / (number of listed edges into i)."""
+    a = torch.zeros(num_nodes, num_nodes, dtype=dtype)
+    for k in range(edge_index.shape[1]):
+        a[int(edge_index[1, k]), int(edge_index[0, k])] += 1.0
+    deg = a.sum(dim=1)
+    return a / torch.where(deg > 0, deg, torch.ones_like(deg)).view(-1, 1)
+
+
+def dense_gat_attention(x, edge_index, lin_weight, att_src, att_dst, negative_slope=0.2):
+    """alpha as a dense (N, N) matrix straight from the GAT paper's formula over the edge multiset (A minus loops) + I."""
+    n = x.shape[0]
+    xs = x @ lin_weight.t()
+    cnt = torch.zeros(n, n, dtype=x.dtype)
+    for k in range(edge_index.shape[1]):
+        s, d = int(edge_index[0, k]), int(edge_index[1, k])
+        if s != d:
+            cnt[d, s] += 1.0
+    cnt = cnt + torch.eye(n, dtype=x.dtype)
+    score = torch.nn.functional.leaky_relu((xs @ att_dst.reshape(-1)).view(-1, 1) + (xs @ att_src.reshape(-1)).view(1, -1), negative_slope)
+    w = cnt * torch.exp(score - score.max())
+    return w / w.sum(dim=1, keepdim=True)
+
 
 def dense_gcn_operator(edge_index, edge_weight, num_nodes, dtype=torch.float64):
     """A_hat = D^-1/2 (A + I) D^-1/2 built as a dense matrix straight from the formula;

@@ -19,6 +19,8 @@ Outputs (tests/golden/):
   golden_tgcn_*.npz          G4  TemporalGCN on the TPIMS fixture
   golden_loop.npz            G5  3-snapshot accumulate-then-RMSprop trajectory (run.py semantics)
   golden_convstack_*.npz     G6  ConvStackedTemporalGCN on the TPIMS fixture
+  golden_sage_*.npz          G7  GraphSAGETemporalGCN (TGCN cell with SAGEConv gates) on the TPIMS fixture
+  golden_gat_*.npz           G8  GATTemporal (TGCN cell with GATConv gates) on the TPIMS fixture
   ref_ckpt_in6_out1_epoch50.pt   data fixture: the checkpoint used by golden_regt_ckpt
 """
 from __future__ import annotations
@@ -75,16 +77,51 @@ class ChebConv(nn.Module):
         return graph_ops.cheb_conv(x, edge_index, edge_weight, self.lins[0].weight, self.lins[1].weight, self.bias)
 
 
-class _Inert(nn.Module):
-    def __init__(self, *a, **k):
+class _LinB(nn.Module):
+    def __init__(self, i, o):
         super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.zeros(o))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class SAGEConv(nn.Module):
+    """PyG parameter names (lin_l.weight, lin_l.bias, lin_r.weight) around oracle.graph_ops.sage_conv."""
+
+    def __init__(self, in_channels, out_channels, **kw):
+        super().__init__()
+        assert not kw, kw
+        self.lin_l = _LinB(in_channels, out_channels)
+        self.lin_r = _Lin(in_channels, out_channels)
+
+    def forward(self, x, edge_index, size=None):
+        assert size is None
+        return graph_ops.sage_conv(x, edge_index, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight)
+
+
+class GATConv(nn.Module):
+    """PyG (>= 2.5) parameter names (att_src, att_dst, bias, lin.weight) around oracle.graph_ops.gat_conv."""
+
+    def __init__(self, in_channels, out_channels, **kw):
+        super().__init__()
+        assert not kw, kw
+        self.att_src = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.lin = _Lin(in_channels, out_channels)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def forward(self, x, edge_index, edge_attr=None, size=None):
+        assert edge_attr is None and size is None
+        return graph_ops.gat_conv(x, edge_index, self.lin.weight, self.att_src, self.att_dst, self.bias)
 
 
 def install_standins():
     tg = types.ModuleType("torch_geometric")
     tgnn = types.ModuleType("torch_geometric.nn")
     inits = types.ModuleType("torch_geometric.nn.inits")
-    tgnn.ChebConv, tgnn.GCNConv, tgnn.SAGEConv, tgnn.GATConv = ChebConv, GCNConv, _Inert, _Inert
+    tgnn.ChebConv, tgnn.GCNConv, tgnn.SAGEConv, tgnn.GATConv = ChebConv, GCNConv, SAGEConv, GATConv
     inits.glorot = lambda t: None
     tgnn.inits = inits
     tg.nn = tgnn
@@ -109,6 +146,15 @@ def load_reference_convstack():
         sys.path.insert(0, REF)
     from models.ConvStackedTemporalGCN import ConvStackedTemporalGCN  # noqa
     return ConvStackedTemporalGCN
+
+
+def load_reference_zero_hidden():
+    install_standins()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from models.GraphSAGETemporalGCN import GraphSAGETemporalGCN  # noqa
+    from models.GATTemporal import GATTemporal  # noqa
+    return GraphSAGETemporalGCN, GATTemporal
 
 
 # ---- helpers -------------------------------------------------------------------------------------
@@ -243,6 +289,30 @@ def golden_convstack(CS, fx, t_in, t_out, seed, tag, window=0):
     return float(loss)
 
 
+def golden_zero_hidden(Mod, name, fx, t_in, t_out, seed, tag, window=0):
+    """models/GraphSAGETemporalGCN.py / models/GATTemporal.py on the TPIMS fixture, positional call of
+    run.py:214 ``model(batch.x, batch.edge_index, batch.edge_attr)``."""
+    n = fx["node_data"].shape[0]
+    x = fx["node_data"][:, :, window:window + t_in].contiguous()
+    y = fx["node_data"][:, -1, window + t_in:window + t_in + t_out].contiguous()
+    mod = Mod(node_features=8, num_nodes=n, periods=t_in, output_dim=t_out)
+    sd = omodel.init_params(name, 8, t_in, t_out, num_nodes=n, seed=seed)
+    res = mod.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert list(sd.keys()) == list(mod.state_dict().keys()), (list(sd.keys()), list(mod.state_dict().keys()))
+    mod.zero_grad()
+    pred, hidden = mod(x, fx["edge_index"], fx["edge_attr"])
+    loss = torch.mean((pred - y) ** 2)
+    loss.backward()
+    grads = {n_: p.grad for n_, p in mod.named_parameters()}
+    out = {"t_in": t_in, "t_out": t_out, "seed": seed, "window": window, "pred": pred.detach().numpy(),
+           "hidden": hidden.detach().numpy(), "loss": np.array([float(loss)]), "param_checksum": param_checksum(sd)}
+    out.update(grads_summary(grads))
+    short = "sage" if name == "GraphSAGETemporalGCN" else "gat"
+    np.savez_compressed(os.path.join(OUT, f"golden_{short}_{tag}.npz"), **out)
+    return float(loss)
+
+
 def golden_loop(RegT, fx, t_in=6, t_out=1, seed=5, n_train=3, n_test=2, epochs=2):
     """run.py:163-226 semantics driven on the reference module: accumulate, one RMSprop step/epoch."""
     n = fx["node_data"].shape[0]
@@ -289,6 +359,10 @@ def main():
     CS = load_reference_convstack()
     for t_in, t_out, seed in ((6, 1, 8), (12, 3, 9)):
         print("convstack", t_in, t_out, "loss", golden_convstack(CS, fx, t_in, t_out, seed, f"in{t_in}_out{t_out}"))
+    SAGE, GATT = load_reference_zero_hidden()
+    for t_in, t_out, seed in ((6, 1, 10), (12, 3, 11)):
+        print("graphsage", t_in, t_out, "loss", golden_zero_hidden(SAGE, "GraphSAGETemporalGCN", fx, t_in, t_out, seed, f"in{t_in}_out{t_out}"))
+        print("gat", t_in, t_out, "loss", golden_zero_hidden(GATT, "GATTemporal", fx, t_in, t_out, seed + 2, f"in{t_in}_out{t_out}"))
     print("goldens written to", OUT)
 
 

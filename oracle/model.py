@@ -24,7 +24,7 @@ from typing import Dict, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-from .graph_ops import cheb_conv, gcn_conv
+from .graph_ops import cheb_conv, gat_conv, gcn_conv, sage_conv
 
 Params = Dict[str, torch.Tensor]
 HIDDEN = 256      # models/RegionalTemporalGCN.py:14, models/TemporalGCN.py:12
@@ -72,6 +72,50 @@ def a3tgcn(p: Params, x, edge_index, edge_weight, prefix="tgnn."):
         h = cheb_conv(xt, edge_index, edge_weight, w0, w1, cb)
         acc = acc + probs[t] * tgcn_cell(p, f"{prefix}_base_tgcn.", xt, edge_index, edge_weight, h)
     return acc
+
+
+def tgcn_cell_block(p: Params, prefix: str, x, edge_index, h, block: str):
+    """models/utils.py:163-203 with base block 'graphsage' or 'gat' (:93-100); ``h`` None = zeros (:163-166)."""
+    if h is None:
+        h = torch.zeros(x.shape[0], p[f"{prefix}linear_z.bias"].numel(), dtype=x.dtype)
+
+    def conv(name):
+        q = f"{prefix}conv_{name}."
+        if block == "graphsage":
+            return sage_conv(x, edge_index, p[q + "lin_l.weight"], p[q + "lin_l.bias"], p[q + "lin_r.weight"])
+        return gat_conv(x, edge_index, p[q + "lin.weight"], p[q + "att_src"], p[q + "att_dst"], p[q + "bias"])
+
+    def gate(name, hidden_in):
+        cat = torch.cat([conv(name), hidden_in], dim=1)
+        return cat @ p[f"{prefix}linear_{name}.weight"].t() + p[f"{prefix}linear_{name}.bias"]
+
+    z = torch.sigmoid(gate("z", h))
+    r = torch.sigmoid(gate("r", h))
+    h_tilde = torch.tanh(gate("h", h * r))
+    return z * h + (1 - z) * h_tilde
+
+
+def zero_hidden_a3tgcn(p: Params, x, edge_index, block: str, prefix: str):
+    """models/GraphSAGETemporalGCN.py:88-96 / models/GATTemporal.py:73-82: ``self._base_tgcn(X[:, :, period], edge_index, H)``
+    hands H (None) to TGCN.forward's ``edge_weight`` parameter, so the cell runs on a zero hidden state in every period."""
+    periods = x.shape[2]
+    probs = torch.softmax(p[f"{prefix}_attention"], dim=0)
+    acc = 0
+    for t in range(periods):
+        acc = acc + probs[t] * tgcn_cell_block(p, f"{prefix}_base_tgcn.", x[:, :, t], edge_index, None, block)
+    return acc
+
+
+def graphsage_temporal_gcn(p: Params, x, edge_index, edge_attr=None):
+    """GraphSAGETemporalGCN.forward (models/GraphSAGETemporalGCN.py:24-43) -> (prediction, hidden)."""
+    hidden = zero_hidden_a3tgcn(p, x, edge_index, "graphsage", "tgnn.")
+    return head(p, hidden), hidden
+
+
+def gat_temporal(p: Params, x, edge_index, edge_attr=None):
+    """GATTemporal.forward (models/GATTemporal.py:21-34) -> (prediction, hidden)."""
+    hidden = zero_hidden_a3tgcn(p, x, edge_index, "gat", "gat.")
+    return head(p, hidden), hidden
 
 
 CONVSTACK_HIDDEN = 512   # models/ConvStackedTemporalGCN.py:13
@@ -157,6 +201,35 @@ def init_params(model: str, node_features: int, periods: int, output_dim: int, n
         p["linear1.weight"], p["linear1.bias"] = _linear_init(g, hh, C, dtype)
         p["linear2.weight"], p["linear2.bias"] = _linear_init(g, output_dim, hh, dtype)
         return p
+    if model in ("GraphSAGETemporalGCN", "GATTemporal"):
+        pre = "tgnn." if model == "GraphSAGETemporalGCN" else "gat."
+        p = {f"{pre}_attention": p["tgnn._attention"]}
+        if model == "GraphSAGETemporalGCN":
+            assert num_nodes is not None
+            p[f"{pre}_weight_att1"] = torch.randn(C, 1, generator=g, dtype=dtype) * 0.1
+            p[f"{pre}_weight_att2"] = torch.randn(num_nodes, 1, generator=g, dtype=dtype) * 0.1
+            p[f"{pre}_bias_att1"] = torch.randn(1, 1, generator=g, dtype=dtype)
+            p[f"{pre}_bias_att2"] = torch.randn(1, 1, generator=g, dtype=dtype)
+        for k in "zrh":
+            q = f"{pre}_base_tgcn.conv_{k}."
+            if model == "GraphSAGETemporalGCN":
+                p[q + "lin_l.weight"] = _glorot(g, C, node_features, dtype)
+                p[q + "lin_l.bias"] = torch.randn(C, generator=g, dtype=dtype) * bias_scale
+                p[q + "lin_r.weight"] = _glorot(g, C, node_features, dtype)
+            else:
+                a = math.sqrt(6.0 / (1 + C))
+                p[q + "att_src"] = (torch.rand(1, 1, C, generator=g, dtype=dtype) * 2 - 1) * a
+                p[q + "att_dst"] = (torch.rand(1, 1, C, generator=g, dtype=dtype) * 2 - 1) * a
+                p[q + "bias"] = torch.randn(C, generator=g, dtype=dtype) * bias_scale
+                p[q + "lin.weight"] = _glorot(g, C, node_features, dtype)
+            w, b = _linear_init(g, C, 2 * C, dtype)
+            p[f"{pre}_base_tgcn.linear_{k}.weight"], p[f"{pre}_base_tgcn.linear_{k}.bias"] = w, b
+        if model == "GraphSAGETemporalGCN":        # never-called GCNConv, models/GraphSAGETemporalGCN.py:61-64
+            p[f"{pre}conv.bias"] = torch.randn(C, generator=g, dtype=dtype) * bias_scale
+            p[f"{pre}conv.lin.weight"] = _glorot(g, C, node_features, dtype)
+        p["linear1.weight"], p["linear1.bias"] = _linear_init(g, HEAD_HIDDEN, C, dtype)
+        p["linear2.weight"], p["linear2.bias"] = _linear_init(g, output_dim, HEAD_HIDDEN, dtype)
+        return p
     if model == "RegionalTemporalGCN":
         assert num_nodes is not None
         p["tgnn._weight_att1"] = torch.randn(C, 1, generator=g, dtype=dtype) * 0.1
@@ -186,3 +259,4 @@ def init_params(model: str, node_features: int, periods: int, output_dim: int, n
 UNUSED_PARAMS = ("tgnn._weight_att1", "tgnn._weight_att2", "tgnn._bias_att1", "tgnn._bias_att2")
 UNUSED_PARAMS_TEMPORAL = ("tgnn.linear.weight", "tgnn.linear.bias")
 UNUSED_PARAMS_CONVSTACK = ("tgnn.linear.weight", "tgnn.linear.bias")
+UNUSED_PARAMS_SAGE = UNUSED_PARAMS + ("tgnn.conv.bias", "tgnn.conv.lin.weight")

@@ -8,8 +8,9 @@ from ._lib import RegtError, load as load_library
 from .graph import PreparedGraph, prepare_graph
 from .functional import RegTGCNFunction, regt_gcn_forward, param_names
 from . import ops, data, dist, etl, train, evaluate
-from .nn import A3TGCN, ConvStackedA3TGCN, ConvStackedTemporalGCN, RegionalA3TGCN, RegionalTemporalGCN, TemporalGCN, TGCN
+from .nn import (A3TGCN, GAT, ConvStackedA3TGCN, ConvStackedTemporalGCN, GATTemporal, GraphSAGE, GraphSAGETemporalGCN, RegionalA3TGCN,
+                 RegionalTemporalGCN, TemporalGCN, TGCN)
 
 __all__ = ["RegtError", "load_library", "PreparedGraph", "prepare_graph", "RegTGCNFunction", "regt_gcn_forward",
            "param_names", "RegionalTemporalGCN", "RegionalA3TGCN", "TemporalGCN", "A3TGCN", "TGCN", "ConvStackedTemporalGCN",
-           "ConvStackedA3TGCN"]
+           "ConvStackedA3TGCN", "GraphSAGETemporalGCN", "GraphSAGE", "GATTemporal", "GAT"]

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libregtgcn_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -47,6 +47,16 @@ class Grads(C.Structure):
     _fields_ = _PARAM_FIELDS
 
 
+class Cell0Args(C.Structure):
+    _fields_ = [("a_z", vp), ("a_h", vp), ("kz", C.c_int32), ("kh", C.c_int32), ("gz", vp), ("gh", vp), ("cz", vp), ("ch", vp),
+                ("attention", vp), ("head1_w", vp), ("head1_b", vp), ("head2_w", vp), ("head2_b", vp)]
+
+
+class Cell0Grads(C.Structure):
+    _fields_ = [("a_z", vp), ("a_h", vp), ("gz", vp), ("gh", vp), ("cz", vp), ("ch", vp), ("attention", vp),
+                ("head1_w", vp), ("head1_b", vp), ("head2_w", vp), ("head2_b", vp)]
+
+
 # name, restype, argtypes -- one entry per function declared in include/regtgcn.h
 SIGNATURES = {
     "regt_abi_version": (C.c_int32, []),
@@ -72,6 +82,12 @@ SIGNATURES = {
                                         C.c_size_t, vp]),
     "regt_backward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), C.POINTER(Grads), vp, vp, vp,
                                   vp, vp, C.c_size_t, vp]),
+    "regt_mean_csr": (C.c_int32, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_cell0_workspace_bytes": (C.c_size_t, [C.POINTER(Dims), C.c_int32, C.c_int32]),
+    "regt_cell0_forward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Cell0Args), vp, vp, vp, C.c_size_t, vp]),
+    "regt_cell0_backward": (C.c_int32, [C.POINTER(Dims), C.POINTER(Cell0Args), C.POINTER(Cell0Grads), vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_gat_forward": (C.c_int32, [vp, vp, vp, vp, vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
+    "regt_gat_backward": (C.c_int32, [vp, vp, vp, vp, vp, vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "regt_graph_stats": (C.c_int32, [C.POINTER(C.c_int64)]),
     "regt_profile_enable": (C.c_int32, [C.c_int32]),
     "regt_profile_collect": (C.c_int32, [C.c_char_p, C.c_size_t]),

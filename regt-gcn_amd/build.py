@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libregtgcn_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "spmm.hip", "graph.hip", "cell.hip"]
+SOURCES = ["api.hip", "gemm.hip", "spmm.hip", "graph.hip", "cell.hip", "gat.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "regtgcn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -305,12 +305,36 @@ int compose_forward(const regt_dims& d, const regt_graph& g, const regt_params& 
     return launch_small_gemm_multi(b, st);
 }
 
+// head of every model on the path: relu -> linear1 -> relu -> linear2 (models/RegionalTemporalGCN.py:35-38); y1 (N, H1) is kept
+// for the backward pass
+int head_forward(const regt_dims& d, const regt_params& p, const float* hidden, float* y1, float* pred, hipStream_t st) {
+    const int N = d.N, C = d.C, O = d.O, H1 = d.H1;
+    GemmSegs S{};
+    S.nseg = 1;
+    S.seg[0] = make_seg(hidden, C, p.head1_w, nullptr, C, INT_MAX, C, true, SEG_RELU_A);
+    S.row_div = 1;
+    EpiBiasAct e{y1, H1, p.head1_b, ACT_RELU, 0.f};
+    PROF("head_fwd", st);
+    TRY(launch_gemm_bias_act(S, N, H1, e, st));
+    if (head2_skinny_ok(H1, O, y1, p.head2_w)) {
+        TRY(launch_head2_fwd(y1, p.head2_w, p.head2_b, pred, N, H1, O, st));
+    } else {
+        GemmSegs S2{};
+        S2.nseg = 1;
+        S2.seg[0] = make_seg(y1, H1, p.head2_w, nullptr, H1, INT_MAX, H1, true);
+        S2.row_div = 1;
+        EpiBiasAct e2{pred, O, p.head2_b, ACT_NONE, 0.f};
+        TRY(launch_gemm_bias_act(S2, N, O, e2, st));
+    }
+    return REGT_OK;
+}
+
 // `h_ext` != NULL: the cell's hidden input (M x C, rows node*T + t) comes from the caller (regt_cell_forward); the
 // regional / Cheb embedding stage is skipped and only A_hat x is aggregated (graph = the N rows of A_hat).
 int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, const float* xp_ext,
                  int x_rows, float* pred, float* hidden, const Layout& L, hipStream_t st, bool skip_pack = false,
                  const float* h_ext = nullptr) {
-    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
+    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* H = h_ext ? h_ext : L.h;
     {
@@ -380,26 +404,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         TRY(launch_gemm_candidate(a, st));
     }
     // 5. head: relu -> linear1 -> relu -> linear2
-    {
-        GemmSegs S{};
-        S.nseg = 1;
-        S.seg[0] = make_seg(hidden, C, p.head1_w, nullptr, C, INT_MAX, C, true, SEG_RELU_A);
-        S.row_div = 1;
-        EpiBiasAct e{L.y1, H1, p.head1_b, ACT_RELU, 0.f};
-        PROF("head_fwd", st);
-        TRY(launch_gemm_bias_act(S, N, H1, e, st));
-        if (head2_skinny_ok(H1, O, L.y1, p.head2_w)) {
-            TRY(launch_head2_fwd(L.y1, p.head2_w, p.head2_b, pred, N, H1, O, st));
-        } else {
-            GemmSegs S2{};
-            S2.nseg = 1;
-            S2.seg[0] = make_seg(L.y1, H1, p.head2_w, nullptr, H1, INT_MAX, H1, true);
-            S2.row_div = 1;
-            EpiBiasAct e2{pred, O, p.head2_b, ACT_NONE, 0.f};
-            TRY(launch_gemm_bias_act(S2, N, O, e2, st));
-        }
-    }
-    return REGT_OK;
+    return head_forward(d, p, hidden, L.y1, pred, st);
 }
 
 // out[Nout x Nin] (+ column sums) = P^T Q over uniform chunks, reduced deterministically.
@@ -455,55 +460,64 @@ int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int N
     return q.push(r);
 }
 
+// backward of head_forward: weight / bias gradients of linear2 and linear1 (slabs queued on `rq`) and
+// dOH = (d1 A1) * (hidden > 0) + dhidden, the gradient of the attention-weighted hidden state
+int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr, const float* dpred, const float* dhidden,
+                  const float* hidden, const float* y1, float* d1, float* dOH, int kchunk_head, int nchunks_head,
+                  ReduceQueue& rq, hipStream_t st) {
+    const int N = d.N, C = d.C, O = d.O, H1 = d.H1;
+    const bool skinny = head2_skinny_ok(H1, O, y1, p.head2_w);
+    if (skinny) {
+        float* slab = nullptr;
+        TRY(rq.take((long)nchunks_head * ((long)O * H1 + O), &slab));
+        {
+            PROF("wgrad_head2", st);
+            TRY(launch_head2_wgrad(dpred, y1, slab, N, H1, O, kchunk_head, nchunks_head, 1, st));
+        }
+        WgradReduceArgs r{};
+        r.slab = slab; r.nchunks = nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
+        r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
+        r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
+        TRY(rq.push(r));
+        PROF("head_bwd", st);
+        TRY(launch_head2_bwd(dpred, p.head2_w, y1, d1, N, H1, O, st));
+    } else {
+        TRY(wgrad_full(rq, "wgrad_head2", dpred, O, O, y1, H1, H1, 0, N, kchunk_head, nchunks_head, gr.head2_w, H1, gr.head2_b, st));
+        // d1 = (dpred A2) * (y1 > 0)
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(dpred, O, p.head2_w, nullptr, H1, INT_MAX, O, false);
+        S.row_div = 1;
+        EpiMaskAdd e{d1, H1, y1, H1, nullptr, 0};
+        PROF("head_bwd", st);
+        TRY(launch_gemm_mask_add(S, N, H1, e, st));
+    }
+    TRY(wgrad_full(rq, "wgrad_head1", d1, H1, H1, hidden, C, C, 1, N, kchunk_head, nchunks_head, gr.head1_w, C, gr.head1_b, st));
+    {   // dOH = (d1 A1) * (hidden > 0) + dhidden
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(d1, H1, p.head1_w, nullptr, C, INT_MAX, H1, false);
+        S.row_div = 1;
+        EpiMaskAdd e{dOH, C, hidden, C, dhidden, C};
+        PROF("head_bwd", st);
+        TRY(launch_gemm_mask_add(S, N, C, e, st));
+    }
+    return REGT_OK;
+}
+
 // `h_ext` / `dh_ext` != NULL (regt_cell_backward): the hidden input was supplied by the caller; its gradient is
 // written to dh_ext and the embedding-stage gradients (A0 / A_r / Cheb weights) are skipped.
 int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
                   const float* dpred, const float* dhidden, const float* hidden, const float* xp_ext, const Layout& L,
                   hipStream_t st, const float* h_ext = nullptr, float* dh_ext = nullptr) {
-    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
+    const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* Xp = xp_ext ? xp_ext : L.Xp;
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
     // ---- head ----------------------------------------------------------------------------------
     ReduceQueue rq(L.slab, L.slab_floats, st);
-    const bool skinny = head2_skinny_ok(H1, O, L.y1, p.head2_w);
-    if (skinny) {
-        float* slab = nullptr;
-        TRY(rq.take((long)L.nchunks_head * ((long)O * H1 + O), &slab));
-        {
-            PROF("wgrad_head2", st);
-            TRY(launch_head2_wgrad(dpred, L.y1, slab, N, H1, O, L.kchunk_head, L.nchunks_head, 1, st));
-        }
-        WgradReduceArgs r{};
-        r.slab = slab; r.nchunks = L.nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
-        r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
-        r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
-        TRY(rq.push(r));
-        PROF("head_bwd", st);
-        TRY(launch_head2_bwd(dpred, p.head2_w, L.y1, L.d1, N, H1, O, st));
-    } else {
-        TRY(wgrad_full(rq, "wgrad_head2", dpred, O, O, L.y1, H1, H1, 0, N, L.kchunk_head, L.nchunks_head, gr.head2_w, H1, gr.head2_b, st));
-    }
-    if (!skinny) {   // d1 = (dpred A2) * (y1 > 0)
-        GemmSegs S{};
-        S.nseg = 1;
-        S.seg[0] = make_seg(dpred, O, p.head2_w, nullptr, H1, INT_MAX, O, false);
-        S.row_div = 1;
-        EpiMaskAdd e{L.d1, H1, L.y1, H1, nullptr, 0};
-        PROF("head_bwd", st);
-        TRY(launch_gemm_mask_add(S, N, H1, e, st));
-    }
-    TRY(wgrad_full(rq, "wgrad_head1", L.d1, H1, H1, hidden, C, C, 1, N, L.kchunk_head, L.nchunks_head, gr.head1_w, C, gr.head1_b, st));
-    {   // dOH = (d1 A1) * (hidden > 0) + dhidden
-        GemmSegs S{};
-        S.nseg = 1;
-        S.seg[0] = make_seg(L.d1, H1, p.head1_w, nullptr, C, INT_MAX, H1, false);
-        S.row_div = 1;
-        EpiMaskAdd e{L.dOH, C, hidden, C, dhidden, C};
-        PROF("head_bwd", st);
-        TRY(launch_gemm_mask_add(S, N, C, e, st));
-    }
+    TRY(head_backward(d, p, gr, dpred, dhidden, hidden, L.y1, L.d1, L.dOH, L.kchunk_head, L.nchunks_head, rq, st));
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
@@ -730,7 +744,7 @@ int32_t regt_pack_x(const float* x, float* xp, int32_t N, int32_t F, int32_t T, 
 int32_t regt_linear(const float* A, int64_t lda, int64_t M, int32_t K, const float* W, int64_t ldw, int32_t N,
                     const float* bias, int32_t act, float slope, float* out, int64_t ldo, regt_stream_t st) {
     REGT_CHECK_ARG(A && W && out && M > 0 && K > 0 && N > 0, "regt_linear: bad argument");
-    REGT_CHECK_ARG(act >= 0 && act <= 2, "regt_linear: act must be 0, 1 or 2");
+    REGT_CHECK_ARG(act >= 0 && act <= 4, "regt_linear: act must be 0 (none), 1 (leaky_relu), 2 (relu), 3 (sigmoid) or 4 (tanh)");
     GemmSegs S{};
     S.nseg = 1;
     S.seg[0] = make_seg(A, lda, W, nullptr, ldw, INT_MAX, K, true);
@@ -879,6 +893,151 @@ int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const
     Layout L = make_layout(*dims, 0, 0, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, nullptr, L, (hipStream_t)st, h_in, dh_in);
+}
+
+/* ---- zero-hidden cell (GraphSAGE / GAT models of the reference) ---------------------------------------------------------- */
+namespace regt { namespace {
+struct Layout0 {
+    float *Z, *Ht, *y1, *probs, *dOH, *d1, *dzp, *dhp, *dp_partial, *slab;
+    int kchunk, nchunks, kchunk_head, nchunks_head, cb_npb, cb_blocks;
+    long slab_floats;
+    size_t bytes;
+};
+Layout0 make_layout0(const regt_dims& d, int kz, int kh, char* base) {
+    Layout0 L{};
+    const long N = d.N, T = d.T, C = d.C, O = d.O, H1 = d.H1, M = N * T;
+    size_t off = 0;
+    auto take = [&](long nfloats) {
+        size_t o = off;
+        off += ((size_t)nfloats * 4 + 255) & ~size_t(255);
+        return base ? reinterpret_cast<float*>(base + o) : nullptr;
+    };
+    L.Z = take(M * C); L.Ht = take(M * C); L.y1 = take(N * H1); L.probs = take(T);
+    L.dOH = take(N * C); L.d1 = take(N * H1); L.dzp = take(M * C); L.dhp = take(M * C);
+    long ks = ((M + 511) / 512 + 31) / 32 * 32;           // skinny (C x k) gradients: memory-bound, many small workgroups
+    if (ks < 128) ks = 128;
+    L.kchunk = (int)ks; L.nchunks = (int)((M + ks - 1) / ks);
+    long kh_ = ((N + 63) / 64 + 31) / 32 * 32;
+    if (kh_ < 512) kh_ = 512;
+    L.kchunk_head = (int)kh_; L.nchunks_head = (int)((N + kh_ - 1) / kh_);
+    L.cb_npb = (int)((N + 2047) / 2048);
+    L.cb_npb = (L.cb_npb + 3) / 4 * 4;
+    L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
+    L.dp_partial = take((long)L.cb_blocks * T);
+    L.slab_floats = (long)L.nchunks * (C * kz + C) + (long)L.nchunks * (C * kh + C) + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64;
+    L.slab = take(L.slab_floats);
+    L.bytes = off;
+    return L;
+}
+int check_cell0(const regt_dims* d, const regt_cell0_args* a) {
+    REGT_CHECK_ARG(d && a, "regt_cell0: NULL dims / args");
+    REGT_CHECK_ARG(d->N > 0 && d->T > 0 && d->C > 0 && d->O > 0 && d->H1 > 0 && d->C % 4 == 0 && d->T <= 64, "regt_cell0: bad dims");
+    REGT_CHECK_ARG((long)d->N * d->T < (1L << 31), "regt_cell0: N*T too large");
+    REGT_CHECK_ARG(a->kz > 0 && a->kh > 0 && a->a_z && a->a_h && a->gz && a->gh && a->cz && a->ch && a->attention && a->head1_w &&
+                   a->head1_b && a->head2_w && a->head2_b, "regt_cell0: a required pointer is NULL");
+    return REGT_OK;
+}
+regt_params head_params(const regt_cell0_args& a) {
+    regt_params p{};
+    p.head1_w = a.head1_w; p.head1_b = a.head1_b; p.head2_w = a.head2_w; p.head2_b = a.head2_b;
+    return p;
+}
+}}  // namespace regt::(anonymous)
+
+size_t regt_cell0_workspace_bytes(const regt_dims* dims, int32_t kz, int32_t kh) {
+    if (!dims || dims->N <= 0 || dims->T <= 0 || dims->C <= 0 || dims->O <= 0 || dims->H1 <= 0 || kz <= 0 || kh <= 0) return 0;
+    return make_layout0(*dims, kz, kh, nullptr).bytes;
+}
+
+int32_t regt_cell0_forward(const regt_dims* dims, const regt_cell0_args* args, float* pred, float* hidden, void* ws, size_t ws_bytes,
+                           regt_stream_t st_) {
+    TRY(check_cell0(dims, args));
+    REGT_CHECK_ARG(pred && hidden && ws && al16(hidden) && al16(ws), "regt_cell0_forward: NULL / unaligned pointer");
+    const regt_dims& d = *dims;
+    const regt_cell0_args& a = *args;
+    Layout0 L = make_layout0(d, a.kz, a.kh, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell0_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    hipStream_t st = (hipStream_t)st_;
+    const long M = (long)d.N * d.T;
+    TRY(launch_softmax_small(a.attention, L.probs, d.T, st));
+    for (int k = 0; k < 2; ++k) {      // Z = sigmoid(a_z gz^T + cz), H~ = tanh(a_h gh^T + ch)
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(k ? a.a_h : a.a_z, k ? a.kh : a.kz, k ? a.gh : a.gz, nullptr, k ? a.kh : a.kz, INT_MAX, k ? a.kh : a.kz, true);
+        S.row_div = 1;
+        EpiBiasAct e{k ? L.Ht : L.Z, d.C, k ? a.ch : a.cz, k ? ACT_TANH : ACT_SIGMOID, 0.f};
+        PROF(k ? "cell0_candidate" : "cell0_gate", st);
+        TRY(launch_gemm_bias_act(S, M, d.C, e, st));
+    }
+    {
+        PROF("cell0_blend", st);
+        TRY(launch_blend0_fwd(L.Z, L.Ht, L.probs, hidden, d.N, d.T, d.C, st));
+    }
+    return head_forward(d, head_params(a), hidden, L.y1, pred, st);
+}
+
+int32_t regt_cell0_backward(const regt_dims* dims, const regt_cell0_args* args, const regt_cell0_grads* grads, const float* dpred,
+                            const float* dhidden, const float* hidden, void* ws, size_t ws_bytes, regt_stream_t st_) {
+    TRY(check_cell0(dims, args));
+    REGT_CHECK_ARG(grads && dpred && hidden && ws, "regt_cell0_backward: NULL pointer");
+    const regt_cell0_grads& g = *grads;
+    REGT_CHECK_ARG(g.gz && g.gh && g.cz && g.ch && g.head1_w && g.head1_b && g.head2_w && g.head2_b,
+                   "regt_cell0_backward: a required gradient pointer is NULL (only attention, a_z, a_h may be NULL)");
+    const regt_dims& d = *dims;
+    const regt_cell0_args& a = *args;
+    Layout0 L = make_layout0(d, a.kz, a.kh, (char*)ws);
+    REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell0_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    hipStream_t st = (hipStream_t)st_;
+    const int N = d.N, T = d.T, C = d.C;
+    const long M = (long)N * T;
+    ReduceQueue rq(L.slab, L.slab_floats, st);
+    regt_grads hg{};
+    hg.head1_w = g.head1_w; hg.head1_b = g.head1_b; hg.head2_w = g.head2_w; hg.head2_b = g.head2_b;
+    TRY(head_backward(d, head_params(a), hg, dpred, dhidden, hidden, L.y1, L.d1, L.dOH, L.kchunk_head, L.nchunks_head, rq, st));
+    {   // dhp = g (1-Z)(1-H~^2), dzp = -g H~ Z (1-Z), g = p_t dOH: the GRU backward head with h = 0
+        CellBwdArgs c{L.dOH, L.probs, L.Z, nullptr, L.Ht, L.dhp, L.dzp, L.dp_partial, N, T, C, L.cb_npb};
+        c.ldz = C; c.lddz = C;
+        PROF("cell_bwd", st);
+        TRY(launch_cell_bwd(c, st));
+        if (g.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, g.attention, T, st));
+    }
+    TRY(wgrad_full(rq, "wgrad_gz", L.dzp, C, C, a.a_z, a.kz, a.kz, 0, M, L.kchunk, L.nchunks, g.gz, a.kz, g.cz, st));
+    TRY(wgrad_full(rq, "wgrad_gh", L.dhp, C, C, a.a_h, a.kh, a.kh, 0, M, L.kchunk, L.nchunks, g.gh, a.kh, g.ch, st));
+    TRY(rq.flush());
+    for (int k = 0; k < 2; ++k) {      // optional input gradients: da = dpre G  (M x C) (C x k)
+        float* da = k ? g.a_h : g.a_z;
+        if (!da) continue;
+        const int kk = k ? a.kh : a.kz;
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(k ? L.dhp : L.dzp, C, k ? a.gh : a.gz, nullptr, kk, INT_MAX, C, false);
+        S.row_div = 1;
+        EpiBiasAct e{da, kk, nullptr, ACT_NONE, 0.f};
+        PROF("cell0_dinput", st);
+        TRY(launch_gemm_bias_act(S, M, kk, e, st));
+    }
+    return REGT_OK;
+}
+
+int32_t regt_gat_forward(const int32_t* rowptr, const int32_t* col, const float* x, const float* u_src, const float* u_dst, float slope,
+                         int32_t N, int32_t T, int32_t F, float* out, float* stats, regt_stream_t st) {
+    REGT_CHECK_ARG(rowptr && col && x && u_src && u_dst && out && stats, "regt_gat_forward: NULL pointer");
+    REGT_CHECK_ARG(al16(x) && al16(u_src) && al16(u_dst) && al16(out) && al16(stats), "regt_gat_forward: pointers must be 16-byte aligned");
+    return launch_gat_forward(rowptr, col, x, u_src, u_dst, slope, N, T, F, out, stats, (hipStream_t)st);
+}
+
+int32_t regt_gat_backward(const int32_t* rowptr, const int32_t* col, const int32_t* t_rowptr, const int32_t* t_col, const float* x,
+                          const float* u_src, float slope, int32_t N, int32_t T, int32_t F, const float* dout, float* stats, float* dsd,
+                          regt_stream_t st) {
+    REGT_CHECK_ARG(rowptr && col && t_rowptr && t_col && x && u_src && dout && stats && dsd, "regt_gat_backward: NULL pointer");
+    REGT_CHECK_ARG(al16(x) && al16(u_src) && al16(dout) && al16(stats), "regt_gat_backward: pointers must be 16-byte aligned");
+    return launch_gat_backward(rowptr, col, t_rowptr, t_col, x, u_src, slope, N, T, F, dout, stats, dsd, (hipStream_t)st);
+}
+
+int32_t regt_mean_csr(const int64_t* ei, int64_t E, int32_t N, int32_t* rowptr, int32_t* col, float* val, int32_t* flags_dev, void* ws,
+                      size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && rowptr && col && val && flags_dev && ws, "regt_mean_csr: NULL pointer");
+    return graph_mean_csr(ei, (long)E, N, rowptr, col, val, flags_dev, ws, ws_bytes, (hipStream_t)st);
 }
 
 int32_t regt_profile_enable(int32_t on) {

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
     for (int t = lane; t < a.T; t += 64) dp[wid][t] = 0.f;
     const long C = a.C;
     const int C4 = a.C / 4;
+    const long ldz = a.ldz ? a.ldz : 2 * C, lddz = a.lddz ? a.lddz : 2 * C;
     const int n0 = blockIdx.x * a.nodes_per_block;
     const int n1 = n0 + a.nodes_per_block < a.num_nodes ? n0 + a.nodes_per_block : a.num_nodes;
     for (int node = n0 + wid; node < n1; node += 4) {
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
             float dot = 0.f;
             for (int c4 = lane; c4 < C4; c4 += 64) {
                 const float4 d = reinterpret_cast<const float4*>(a.dOH + node * C)[c4];
-                const float4 z = reinterpret_cast<const float4*>(a.ZR + m * 2 * C)[c4];
-                const float4 h = reinterpret_cast<const float4*>(a.h + m * C)[c4];
+                const float4 z = reinterpret_cast<const float4*>(a.ZR + m * ldz)[c4];
+                const float4 h = a.h ? reinterpret_cast<const float4*>(a.h + m * C)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 ht = reinterpret_cast<const float4*>(a.Ht + m * C)[c4];
                 float4 dhp, dzp;
 #define REGT_CB(x)                                                   \
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
                 REGT_CB(x) REGT_CB(y) REGT_CB(z) REGT_CB(w)
 #undef REGT_CB
                 reinterpret_cast<float4*>(a.dhp + m * C)[c4] = dhp;
-                reinterpret_cast<float4*>(a.dzr + m * 2 * C)[c4] = dzp;
+                reinterpret_cast<float4*>(a.dzr + m * lddz)[c4] = dzp;
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
@@ -70,6 +71,38 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
 }
 
 int cell_bwd_blocks(int num_nodes, int nodes_per_block) { return cdiv(num_nodes, nodes_per_block); }
+
+// Zero-hidden cell (the reference's GraphSAGE / GAT models call the cell with H = None -> zeros, models/utils.py:163-166):
+// H' = Z * 0 + (1 - Z) * H~, summed over the T periods with the attention probabilities.  One wave per node, lanes over C.
+__global__ __launch_bounds__(256) void blend0_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ Ht,
+                                                         const float* __restrict__ probs, float* __restrict__ hidden,
+                                                         int num_nodes, int T, int C4) {
+    const int lane = threadIdx.x & 63;
+    const long waves = (long)gridDim.x * 4;
+    for (long node = (long)blockIdx.x * 4 + (threadIdx.x >> 6); node < num_nodes; node += waves) {
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < T; ++t) {
+                const long m = node * T + t;
+                const float p = probs[t];
+                const float4 z = reinterpret_cast<const float4*>(Z)[m * C4 + c4];
+                const float4 h = reinterpret_cast<const float4*>(Ht)[m * C4 + c4];
+                acc.x += p * ((1.0f - z.x) * h.x); acc.y += p * ((1.0f - z.y) * h.y);
+                acc.z += p * ((1.0f - z.z) * h.z); acc.w += p * ((1.0f - z.w) * h.w);
+            }
+            reinterpret_cast<float4*>(hidden)[node * C4 + c4] = acc;
+        }
+    }
+}
+
+int launch_blend0_fwd(const float* Z, const float* Ht, const float* probs, float* hidden, int num_nodes, int T, int C, hipStream_t st) {
+    REGT_CHECK_ARG(C % 4 == 0 && num_nodes > 0 && T > 0, "blend0: bad shape");
+    int blocks = cdiv(num_nodes, 4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(blend0_fwd_kernel, dim3(blocks), dim3(256), 0, st, Z, Ht, probs, hidden, num_nodes, T, C / 4);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
 
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.T <= CB_MAXT, "cell_bwd: T=%d exceeds %d", a.T, CB_MAXT);

@@ -37,8 +37,11 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 
 struct EpiBiasActF {
     EpiBiasAct e;
-    // none / leaky_relu / relu are all "v > 0 ? v : v * ns" with ns = 1 / slope / 0
+    // none / leaky_relu / relu are all "v > 0 ? v : v * ns" with ns = 1 / slope / 0; sigmoid / tanh for the gate GEMMs of the
+    // zero-hidden cell (regt_cell0_forward)
     __device__ __forceinline__ float act(float v) const {
+        if (e.act == ACT_SIGMOID) return fast_sigmoid(v);
+        if (e.act == ACT_TANH) return fast_tanh(v);
         const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
         return v > 0.f ? v : v * ns;
     }

@@ -34,23 +34,41 @@ constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
 // [rmin, rmax] walk minus the regions that contributed only zeros, so sums are unchanged bit for bit.
 template <int BMT>
 __device__ __forceinline__ const int* tile_regions(const GemmSegs& S, const RowMap& rm, int* red, int tid) {
+    // red[4..8): per-wave masks of the rows that START a run of equal regions; red[8 ..): region of each row, then the list.
+    // Thread 0 only visits the run starts (one or two per tile when node ids are sorted by region) and inserts their
+    // regions into a sorted, duplicate-free list.
+    static_assert(BMT <= 128, "two waves of row flags");
     int* rowreg = red + 8;
     int* list = red + 8 + BMT;
-    if (tid < BMT && tid < rm.nvalid) rowreg[tid] = S.node_region[rm.grow(tid) / S.row_div];
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(red + 4);
+    const int nv = rm.nvalid < BMT ? rm.nvalid : BMT;
+    int reg = -1;
+    if (tid < nv) {
+        reg = S.node_region[rm.grow(tid) / S.row_div];
+        rowreg[tid] = reg;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const bool first = tid < nv && (tid == 0 || rowreg[tid - 1] != reg);
+        const unsigned long long m = __ballot(first);
+        if ((tid & 63) == 0) masks[tid >> 6] = m;
+    }
     __syncthreads();
     if (tid == 0) {
-        int n = 0, last = -1;
-        const int nv = rm.nvalid < BMT ? rm.nvalid : BMT;
-        for (int r = 0; r < nv; ++r) {
-            const int reg = rowreg[r];
-            if (reg == last) continue;
-            last = reg;
-            int pos = 0;
-            while (pos < n && list[pos] < reg) ++pos;
-            if (pos < n && list[pos] == reg) continue;
-            for (int j = n; j > pos; --j) list[j] = list[j - 1];
-            list[pos] = reg;
-            ++n;
+        int n = 0;
+        for (int w = 0; w < 2; ++w) {
+            unsigned long long m = masks[w];
+            while (m) {
+                const int r = 64 * w + __builtin_ctzll(m);
+                m &= m - 1;
+                const int rg = rowreg[r];
+                int pos = 0;
+                while (pos < n && list[pos] < rg) ++pos;
+                if (pos < n && list[pos] == rg) continue;
+                for (int j = n; j > pos; --j) list[j] = list[j - 1];
+                list[pos] = rg;
+                ++n;
+            }
         }
         red[3] = n;
     }

@@ -23,11 +23,11 @@ __global__ void k_fill_int(int* p, long n, int v) {
 
 // count edges per key (key_row: 0 = source, 1 = destination); self loops are skipped and, when
 // loop_eid != nullptr, the largest edge id of each node's own loops is recorded ("last one wins").
-__global__ void k_count(const int64_t* ei, long E, int N, int key_row, int* cnt, int* loop_eid, int* bad) {
+__global__ void k_count(const int64_t* ei, long E, int N, int key_row, int* cnt, int* loop_eid, int* bad, int keep_loops) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         int64_t s = ei[e], d = ei[E + e];
         if (s < 0 || s >= N || d < 0 || d >= N) { atomicOr(bad, 1); continue; }
-        if (s == d) { if (loop_eid) atomicMax(&loop_eid[s], (int)e); continue; }
+        if (s == d && !keep_loops) { if (loop_eid) atomicMax(&loop_eid[s], (int)e); continue; }
         atomicAdd(&cnt[key_row ? d : s], 1);
     }
 }
@@ -53,10 +53,10 @@ __global__ __launch_bounds__(1024) void k_scan(const int* cnt, int N, int extra,
     if (tid == 1023) ptr[N] = (int)part[1023];
 }
 
-__global__ void k_bucket(const int64_t* ei, long E, int N, int key_row, const int* ptr, int* cursor, int* eid) {
+__global__ void k_bucket(const int64_t* ei, long E, int N, int key_row, const int* ptr, int* cursor, int* eid, int keep_loops) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
         int64_t s = ei[e], d = ei[E + e];
-        if (s < 0 || s >= N || d < 0 || d >= N || s == d) continue;
+        if (s < 0 || s >= N || d < 0 || d >= N || (s == d && !keep_loops)) continue;
         int k = (int)(key_row ? d : s);
         eid[ptr[k] + atomicAdd(&cursor[k], 1)] = (int)e;
     }
@@ -167,6 +167,19 @@ __global__ void k_emit_raw(const int64_t* ei, long E, const float* w, const int*
     }
 }
 
+// mean aggregation rows (SAGEConv aggr='mean'): every listed in-edge j -> i, self loops and duplicates included as listed,
+// weight 1 / (number of in-edges of i)
+__global__ void k_emit_mean(const int64_t* ei, long E, const int* ptr, const int* cnt, const int* eid, int N, int* col, float* val) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        const int b = ptr[i], n = cnt[i];
+        const float w = n > 0 ? 1.0f / (float)n : 0.f;
+        for (int p = 0; p < n; ++p) {
+            col[b + p] = (int)ei[eid[b + p]];
+            val[b + p] = w;
+        }
+    }
+}
+
 __global__ void k_fingerprint(const int64_t* ei, const float* w, long E, unsigned long long* out) {
     unsigned long long h = 0;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long)gridDim.x * blockDim.x) {
@@ -202,13 +215,13 @@ size_t ws_layout(long E, int N, char* base, Ws* w) {
 }
 
 // bucket edges by key into (ptr, eid) inside the workspace; `extra` slots are reserved at the end of each bucket.
-int bucket(const int64_t* ei, long E, int N, int key_row, int extra, const Ws& w, int* ptr_out, hipStream_t st) {
+int bucket(const int64_t* ei, long E, int N, int key_row, int extra, const Ws& w, int* ptr_out, hipStream_t st, int keep_loops = 0) {
     hipLaunchKernelGGL(k_fill_int, dim3(nblk(N + 1)), dim3(TPB), 0, st, w.cnt, (long)N + 1, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(nblk(N)), dim3(TPB), 0, st, w.cursor, (long)N, 0);
     hipLaunchKernelGGL(k_fill_int, dim3(nblk(N)), dim3(TPB), 0, st, w.loop_eid, (long)N, -1);
-    if (E > 0) hipLaunchKernelGGL(k_count, dim3(nblk(E)), dim3(TPB), 0, st, ei, E, N, key_row, w.cnt, w.loop_eid, w.flags);
+    if (E > 0) hipLaunchKernelGGL(k_count, dim3(nblk(E)), dim3(TPB), 0, st, ei, E, N, key_row, w.cnt, w.loop_eid, w.flags, keep_loops);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, w.cnt, N, extra, ptr_out);
-    if (E > 0) hipLaunchKernelGGL(k_bucket, dim3(nblk(E)), dim3(TPB), 0, st, ei, E, N, key_row, ptr_out, w.cursor, w.eid);
+    if (E > 0) hipLaunchKernelGGL(k_bucket, dim3(nblk(E)), dim3(TPB), 0, st, ei, E, N, key_row, ptr_out, w.cursor, w.eid, keep_loops);
     hipLaunchKernelGGL(k_sort_buckets, dim3(nblk(N)), dim3(TPB), 0, st, ptr_out, w.cnt, N, w.eid);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
@@ -261,6 +274,21 @@ int graph_raw_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr,
     int rc = bucket(ei, E, N, 1, 0, W, rowptr, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_emit_raw, dim3(nblk(N)), dim3(TPB), 0, st, ei, E, w, rowptr, W.cnt, W.eid, N, col, val);
+    REGT_CHECK_LAUNCH();
+    REGT_CHECK_HIP(hipMemcpyAsync(flags_out_dev, W.flags, 4, hipMemcpyDeviceToDevice, st));
+    return REGT_OK;
+}
+
+int graph_mean_csr(const int64_t* ei, long E, int N, int* rowptr, int* col, float* val, int* flags_out_dev, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+    REGT_CHECK_ARG(N > 0 && E >= 0, "graph: N=%d E=%ld", N, E);
+    REGT_CHECK_ARG(ws_bytes >= graph_workspace_bytes(E, N), "graph: workspace too small");
+    Ws W;
+    ws_layout(E, N, (char*)ws, &W);
+    REGT_CHECK_HIP(hipMemsetAsync(W.flags, 0, 256, st));
+    int rc = bucket(ei, E, N, 1, 0, W, rowptr, st, /*keep_loops=*/1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_emit_mean, dim3(nblk(N)), dim3(TPB), 0, st, ei, E, rowptr, W.cnt, W.eid, N, col, val);
     REGT_CHECK_LAUNCH();
     REGT_CHECK_HIP(hipMemcpyAsync(flags_out_dev, W.flags, 4, hipMemcpyDeviceToDevice, st));
     return REGT_OK;

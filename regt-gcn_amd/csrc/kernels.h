@@ -6,7 +6,7 @@
 namespace regt {
 
 // ---- epilogue descriptors for the flat segmented GEMM ------------------------------------------
-enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2 };
+enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
 
 struct EpiBiasAct {     // out[m, c] = act(v + bias[c])
     float* out; long ldo; const float* bias; int act; float slope;
@@ -134,6 +134,8 @@ int graph_cheb_edge_weights(const int64_t* ei, const float* w, long E, int N, fl
 int graph_raw_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,
                   int* flags_out_dev, void* ws, size_t ws_bytes, hipStream_t st);
 int graph_fingerprint(const int64_t* ei, const float* w, long E, unsigned long long* out_dev, hipStream_t st);
+int graph_mean_csr(const int64_t* ei, long E, int N, int* rowptr, int* col, float* val, int* flags_out_dev, void* ws,
+                   size_t ws_bytes, hipStream_t st);
 
 // ---- sparse aggregation ------------------------------------------------------------------------
 int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st);            // (N,F,T) -> (N,T,F)
@@ -162,10 +164,19 @@ int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st);
 struct CellBwdArgs {
     const float* dOH; const float* probs; const float* ZR; const float* h; const float* Ht;
     float* dhp; float* dzr; float* dp_partial; int num_nodes, T, C; int nodes_per_block;
+    // zero-hidden cell (GraphSAGE / GAT models): h == nullptr means H = 0; Z and dzp then are plain (M, C) arrays
+    int ldz = 0, lddz = 0;     // row strides of ZR and dzr in floats; 0 = 2C ([Z|R] and [dzp|drp] layouts of the GRU cell)
 };
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st);
 int cell_bwd_blocks(int num_nodes, int nodes_per_block);
 int launch_att_bwd(const float* dp_partial, int nblocks, const float* probs, float* datt, int T, hipStream_t st);
+// zero-hidden cell: hidden[n, :] = sum_t probs[t] * (1 - Z[n*T+t, :]) * Ht[n*T+t, :]
+int launch_blend0_fwd(const float* Z, const float* Ht, const float* probs, float* hidden, int num_nodes, int T, int C, hipStream_t st);
+// GATConv attention aggregation on input rows (gat.hip)
+int launch_gat_forward(const int* rowptr, const int* col, const float* x, const float* us, const float* ud, float slope, int N,
+                       int T, int F, float* out, float* stats, hipStream_t st);
+int launch_gat_backward(const int* rowptr, const int* col, const int* t_rowptr, const int* t_col, const float* x, const float* us,
+                        float slope, int N, int T, int F, const float* dout, float* stats, float* dsd, hipStream_t st);
 int launch_copy_f32(float* dst, const float* src, long n, hipStream_t st);
 int launch_zero_f32(float* dst, long n, hipStream_t st);
 int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st);

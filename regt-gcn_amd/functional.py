@@ -380,6 +380,7 @@ class LinearFunction(torch.autograd.Function):
         from . import ops
         ctx.save_for_backward(a, w)
         ctx.need_da = a.requires_grad
+        ctx.has_bias = b is not None
         return ops.linear(a, w, b, 0)
 
     @staticmethod
@@ -388,8 +389,99 @@ class LinearFunction(torch.autograd.Function):
         a, w = ctx.saved_tensors
         dy = dy.contiguous()
         da = ops.linear(dy, w.t().contiguous(), None, 0) if ctx.need_da else None
-        dw, db = ops.wgrad(dy, a)
+        dw, db = ops.wgrad(dy, a, with_bias=ctx.has_bias)
         return da, dw, db
+
+
+class Cell0Function(torch.autograd.Function):
+    """Zero-hidden TGCN cell + attention + head (regt_cell0_forward / regt_cell0_backward):
+    (a_z (M,kz), a_h (M,kh), gz (C,kz), gh (C,kh), cz (C), ch (C), attention (T), linear1.weight, linear1.bias, linear2.weight,
+    linear2.bias, num_nodes) -> (pred (N,O), hidden (N,C))."""
+
+    @staticmethod
+    def forward(ctx, a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b, num_nodes: int):
+        lib = _lib.load()
+        tens = [a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b]
+        for t_ in tens:
+            if not t_.is_cuda or t_.dtype != torch.float32:
+                raise _lib.RegtError("zero-hidden cell needs float32 CUDA/HIP tensors: there is no CPU path in this package")
+        a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b = [t_.contiguous() for t_ in tens]
+        M, kz = a_z.shape
+        kh = a_h.shape[1]
+        T = att.numel()
+        Cdim, O, H1 = gz.shape[0], l2w.shape[0], l1w.shape[0]
+        if M != num_nodes * T or a_h.shape[0] != M or tuple(gz.shape) != (Cdim, kz) or tuple(gh.shape) != (Cdim, kh):
+            raise ValueError("zero-hidden cell: inconsistent shapes")
+        dims = _lib.Dims(num_nodes, T, max(kz, kh), Cdim, 1, O, H1, 0, 0.0)
+        args = _lib.Cell0Args(a_z.data_ptr(), a_h.data_ptr(), kz, kh, gz.data_ptr(), gh.data_ptr(), cz.data_ptr(), ch.data_ptr(),
+                              att.data_ptr(), l1w.data_ptr(), l1b.data_ptr(), l2w.data_ptr(), l2b.data_ptr())
+        wsb = lib.regt_cell0_workspace_bytes(C.byref(dims), kz, kh)
+        if wsb == 0:
+            raise _lib.RegtError("regt_cell0_workspace_bytes: bad dims")
+        handle = _WsHandle(_POOL.acquire(wsb, a_z.device))
+        pred = torch.empty(num_nodes, O, dtype=torch.float32, device=a_z.device)
+        hidden = torch.empty(num_nodes, Cdim, dtype=torch.float32, device=a_z.device)
+        _lib.check(lib.regt_cell0_forward(C.byref(dims), C.byref(args), _lib.ptr(pred), _lib.ptr(hidden), _lib.ptr(handle.ws), wsb,
+                                          _stream()), "regt_cell0_forward")
+        ctx.dims, ctx.args, ctx.ws_handle, ctx.wsb = dims, args, handle, wsb
+        ctx.save_for_backward(hidden, a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b)
+        return pred, hidden
+
+    @staticmethod
+    def backward(ctx, dpred, dhidden):
+        lib = _lib.load()
+        hidden, a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b = ctx.saved_tensors
+        dims = ctx.dims
+        dev = hidden.device
+        if dpred is None:
+            dpred = torch.zeros(dims.N, dims.O, dtype=torch.float32, device=dev)
+        dpred = dpred.contiguous()
+        dhid = None if dhidden is None else dhidden.contiguous()
+        need_az, need_ah = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_az = torch.empty_like(a_z) if need_az else None
+        d_ah = torch.empty_like(a_h) if need_ah else None
+        g = [torch.empty_like(t_) for t_ in (gz, gh, cz, ch, att, l1w, l1b, l2w, l2b)]
+        gr = _lib.Cell0Grads(_lib.ptr(d_az), _lib.ptr(d_ah), *[t_.data_ptr() for t_ in g])
+        _lib.check(lib.regt_cell0_backward(C.byref(dims), C.byref(ctx.args), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
+                                           _lib.ptr(hidden), _lib.ptr(ctx.ws_handle.ws), ctx.wsb, _stream()), "regt_cell0_backward")
+        return (d_az, d_ah, *g, None)
+
+
+class GatAggregateFunction(torch.autograd.Function):
+    """out (N,T,F) = attention-weighted neighbour sum of GATConv on packed input rows (regt_gat_forward); the backward returns
+    the gradients of the two score vectors u_src, u_dst (F) -- the input rows are data."""
+
+    @staticmethod
+    def forward(ctx, xp, u_src, u_dst, pattern, slope: float):
+        from . import ops
+        out, stats = ops.gat_forward(pattern.rowptr, pattern.col, xp, u_src, u_dst, slope)
+        ctx.pattern, ctx.slope = pattern, slope
+        ctx.save_for_backward(xp, u_src.contiguous(), stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import ops
+        xp, u_src, stats = ctx.saved_tensors
+        p = ctx.pattern
+        n, t, f = xp.shape
+        dsd = ops.gat_backward(p.rowptr, p.col, p.t_rowptr, p.t_col, xp, u_src, dout.contiguous(), stats, ctx.slope)
+        du, _ = ops.wgrad(dsd, xp.view(n * t, f), with_bias=False)          # (2, F) = dsd^T x
+        return None, du[0].contiguous(), du[1].contiguous(), None, None
+
+
+class ZeroGradAnchor(torch.autograd.Function):
+    """Identity on ``out`` that gives ``dead`` parameters an all-zero gradient: in the reference's GraphSAGE / GAT models the
+    reset gate is computed and multiplied by the zero hidden state, so autograd hands its parameters zeros, not None."""
+
+    @staticmethod
+    def forward(ctx, out, *dead):
+        ctx.shapes = [(d.shape, d.device) for d in dead]
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g, *[torch.zeros(s, dtype=torch.float32, device=dv) for s, dv in ctx.shapes])
 
 
 def regt_gcn_forward(x, graph: PreparedGraph, params: Dict[str, torch.Tensor], regional: bool = True, slope: float = 0.01):

@@ -153,6 +153,56 @@ def raw_csr(edge_index: torch.Tensor, edge_value: torch.Tensor, num_nodes: int):
     return rowptr, col[:nnz], val[:nnz]
 
 
+def mean_csr(edge_index: torch.Tensor, num_nodes: int):
+    """Mean-aggregation operator of SAGEConv (every listed in-edge, weight 1 / in-degree) as (rowptr, col, val)."""
+    lib = _lib.load()
+    _check_edges(edge_index, None, "mean_csr")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    e = ei.shape[1]
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    val = torch.empty(max(e, 1), dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.regt_graph_workspace_bytes(e, num_nodes)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.regt_mean_csr(_lib.ptr(ei), e, num_nodes, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val), _lib.ptr(flags),
+                                 _lib.ptr(ws), wsb, _stream()), "regt_mean_csr")
+    _raise_flags(flags, "mean_csr")
+    nnz = int(rowptr[-1].item())
+    return rowptr, col[:nnz], val[:nnz]
+
+
+@dataclass
+class MeanOperator:
+    """SAGEConv's mean-neighbour operator of one static graph (input aggregation only: no transposed copy needed)."""
+    num_nodes: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    val: torch.Tensor
+
+
+@dataclass
+class AttentionPattern:
+    """Sparsity pattern of GATConv's attention (in-edges without self loops + one self loop per node) and its transpose."""
+    num_nodes: int
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    t_rowptr: torch.Tensor
+    t_col: torch.Tensor
+
+
+def prepare_mean_operator(edge_index: torch.Tensor, num_nodes: int) -> MeanOperator:
+    rp, col, val = mean_csr(edge_index, num_nodes)
+    return MeanOperator(num_nodes, rp, col, val)
+
+
+def prepare_attention_pattern(edge_index: torch.Tensor, num_nodes: int) -> AttentionPattern:
+    rp, col, val = gcn_csr(edge_index, None, num_nodes)          # the pattern of gcn_norm = remove + add self loops
+    t = transpose_csr(rp, col, val, num_nodes, num_nodes)
+    return AttentionPattern(num_nodes, rp, col, t[0], t[1])
+
+
 def fingerprint(tensors: Sequence[Optional[torch.Tensor]]) -> int:
     """Content hash of a list of (edge_index, weight) style tensors -- one device pass + one 8-byte readback."""
     lib = _lib.load()

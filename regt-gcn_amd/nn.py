@@ -23,22 +23,25 @@ import torch.nn as nn
 
 from . import _lib
 from . import ops
-from .functional import (HEAD_HIDDEN, PARAM_NAMES_CELL, AggregateFunction, CellFunction, LinearFunction, RegTGCNFunction,
-                         param_names)
-from .graph import GcnOperator, PreparedGraph, fingerprint, prepare_gcn_operator, prepare_graph
+from .functional import (HEAD_HIDDEN, PARAM_NAMES_CELL, AggregateFunction, Cell0Function, CellFunction, GatAggregateFunction,
+                         LinearFunction, RegTGCNFunction, ZeroGradAnchor, param_names)
+from .graph import (AttentionPattern, GcnOperator, MeanOperator, PreparedGraph, fingerprint, prepare_attention_pattern,
+                    prepare_gcn_operator, prepare_graph, prepare_mean_operator)
 
 HIDDEN = 256          # out_channels=256, models/RegionalTemporalGCN.py:14 / models/TemporalGCN.py:12
 LEAKY_SLOPE = 0.01    # F.leaky_relu default, models/RegionalTemporalGCN.py:143
 
 
 class _PygLinear(nn.Module):
-    """Bias-free linear parameter holder named like torch_geometric's Linear (``.weight`` (out,in), glorot)."""
+    """Linear parameter holder named like torch_geometric's Linear (``.weight`` (out,in) glorot; optional zero ``.bias``)."""
 
-    def __init__(self, in_channels: int, out_channels: int):
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = False):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
         a = math.sqrt(6.0 / (in_channels + out_channels))
         nn.init.uniform_(self.weight, -a, a)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
 
 
 class _GCNConvParams(nn.Module):
@@ -59,20 +62,47 @@ class _ChebConvParams(nn.Module):
         self.lins = nn.ModuleList([_PygLinear(in_channels, out_channels) for _ in range(2)])
 
 
+class _SAGEConvParams(nn.Module):
+    """Parameters of a PyG SAGEConv(aggr='mean', root_weight=True): ``lin_l.weight/.bias`` (neighbour mean) and ``lin_r.weight``."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.lin_l = _PygLinear(in_channels, out_channels, bias=True)
+        self.lin_r = _PygLinear(in_channels, out_channels)
+
+
+class _GATConvParams(nn.Module):
+    """Parameters of a PyG GATConv(heads=1): ``att_src``, ``att_dst`` (1,1,C), ``bias`` (C), ``lin.weight`` (C,F) -- the layout
+    of PyG >= 2.5, where an int ``in_channels`` shares one projection ``lin`` (2.0-2.4 call it lin_src / lin_dst)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        a = math.sqrt(6.0 / (1 + out_channels))
+        self.att_src = nn.Parameter(torch.empty(1, 1, out_channels).uniform_(-a, a))
+        self.att_dst = nn.Parameter(torch.empty(1, 1, out_channels).uniform_(-a, a))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.lin = _PygLinear(in_channels, out_channels)
+
+
 class TGCN(nn.Module):
-    """Parameter layout of the reference's T-GCN GRU cell (models/utils.py:75-161, baseblock 'gcn')."""
+    """Parameter layout of the reference's T-GCN GRU cell (models/utils.py:75-161) for its three base blocks: 'gcn'
+    (GCNConv, the hot path), 'graphsage' (SAGEConv) and 'gat' (GATConv) (:93-100)."""
 
     def __init__(self, in_channels: int, out_channels: int, baseblock: str = "gcn", improved: bool = False,
                  cached: bool = False, add_self_loops: bool = True):
         super().__init__()
-        if baseblock != "gcn" or improved or not add_self_loops:
-            raise NotImplementedError("only baseblock='gcn', improved=False, add_self_loops=True is on the hot path")
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.conv_z = _GCNConvParams(in_channels, out_channels)
+        if improved or not add_self_loops:
+            raise NotImplementedError("only improved=False, add_self_loops=True is on the hot path")
+        blocks = {"gcn": _GCNConvParams, "graphsage": _SAGEConvParams, "gat": _GATConvParams}
+        if baseblock not in blocks:
+            raise NotImplementedError("Current baseblock %s is not supported." % (baseblock))     # models/utils.py:102
+        conv = blocks[baseblock]
+        self.in_channels, self.out_channels, self.baseblock = in_channels, out_channels, baseblock
+        self.conv_z = conv(in_channels, out_channels)
         self.linear_z = nn.Linear(2 * out_channels, out_channels)
-        self.conv_r = _GCNConvParams(in_channels, out_channels)
+        self.conv_r = conv(in_channels, out_channels)
         self.linear_r = nn.Linear(2 * out_channels, out_channels)
-        self.conv_h = _GCNConvParams(in_channels, out_channels)
+        self.conv_h = conv(in_channels, out_channels)
         self.linear_h = nn.Linear(2 * out_channels, out_channels)
 
 
@@ -307,3 +337,147 @@ class ConvStackedTemporalGCN(nn.Module):
         n = x.shape[0]
         op = self._graphs.get([edge_index, edge_attr], n, lambda: prepare_gcn_operator(edge_index, edge_attr, n))
         return self.forward_prepared(x, op)
+
+
+# ---- GraphSAGE / GAT base blocks of the cell (second half) ---------------------------------------------
+# Both reference models call ``self._base_tgcn(X[:, :, period], edge_index, H)``: TGCN.forward's third positional parameter is
+# ``edge_weight``, so H stays None and the cell starts from zeros in every period (models/utils.py:163-166).  With H = 0 the
+# reset gate only multiplies zeros: Z = sigmoid(U_z1 conv_z(x) + u_z), H~ = tanh(U_h1 conv_h(x) + u_h), H' = (1 - Z) H~
+# -- every contraction has K = F (or 2F), the sparse operators act on the input, and the whole model is one aggregation, two
+# skinny MFMA GEMMs with sigmoid / tanh epilogues, a blend + attention sum and the head (regt_cell0_forward).
+
+def _compose(u1: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """U1 (C,C) @ W (C,K) on the matrix cores with autograd (regt_linear / regt_wgrad)."""
+    return LinearFunction.apply(u1, w.t().contiguous(), None)
+
+
+def _compose_bias(u1: torch.Tensor, b: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    """U1 b + u."""
+    return LinearFunction.apply(b.view(1, -1), u1, None).view(-1) + u
+
+
+class GraphSAGE(nn.Module):
+    """Parameter layout of models/GraphSAGETemporalGCN.py:46-72: TGCN cell with SAGEConv gates, a never-called GCNConv
+    ``conv`` (:61-64), the attention over periods and the dead ``_weight_att*`` / ``_bias_att*`` of the A3T-GCN template."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, periods: int):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_nodes, self.periods = in_channels, out_channels, num_nodes, periods
+        self._attention = nn.Parameter(torch.empty(periods))
+        self._weight_att1 = nn.Parameter(torch.normal(0.0, 0.1, size=(out_channels, 1)))
+        self._weight_att2 = nn.Parameter(torch.normal(0.0, 0.1, size=(num_nodes, 1)))
+        self._bias_att1 = nn.Parameter(torch.normal(0.0, 1.0, size=(1, 1)))
+        self._bias_att2 = nn.Parameter(torch.normal(0.0, 1.0, size=(1, 1)))
+        self._base_tgcn = TGCN(in_channels, out_channels, baseblock="graphsage")
+        self.conv = _GCNConvParams(in_channels, out_channels)
+        nn.init.uniform_(self._attention)
+
+
+class GAT(nn.Module):
+    """Parameter layout of models/GATTemporal.py:37-64: TGCN cell with GATConv gates and the attention over periods."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_nodes: int, periods: int):
+        super().__init__()
+        self.in_channels, self.out_channels, self.num_nodes, self.periods = in_channels, out_channels, num_nodes, periods
+        self._attention = nn.Parameter(torch.empty(periods))
+        self._base_tgcn = TGCN(in_channels, out_channels, baseblock="gat")
+        self.relu = nn.ReLU()
+        nn.init.uniform_(self._attention)
+
+
+class _ZeroHiddenModel(nn.Module):
+    cell_attr: str
+
+    def _cell(self) -> TGCN:
+        return getattr(self, self.cell_attr)._base_tgcn
+
+    def _run_cell0(self, a_z, a_h, gz, gh, cz, ch, num_nodes: int):
+        inner = getattr(self, self.cell_attr)
+        pred, hidden = Cell0Function.apply(a_z, a_h, gz, gh, cz, ch, inner._attention, self.linear1.weight, self.linear1.bias,
+                                           self.linear2.weight, self.linear2.bias, num_nodes)
+        cell = self._cell()
+        dead = list(cell.conv_r.parameters()) + list(cell.linear_r.parameters())     # reset gate: multiplied by H = 0
+        return ZeroGradAnchor.apply(pred, *dead), hidden
+
+
+class GraphSAGETemporalGCN(_ZeroHiddenModel):
+    """GraphSAGE baseline (models/GraphSAGETemporalGCN.py:8-43).  ``forward(x, edge_index, edge_attr)`` ->
+    ``(prediction (N, output_dim), hidden (N, 256))``; ``edge_attr`` is accepted and ignored, as in the reference (:93-95)."""
+
+    cell_attr = "tgnn"
+
+    def __init__(self, node_features: int, num_nodes: int, periods: int, output_dim: int, hidden_channels: int = HIDDEN):
+        super().__init__()
+        self.tgnn = GraphSAGE(node_features, hidden_channels, num_nodes, periods)
+        self.output_dim = output_dim
+        self.linear1 = nn.Linear(hidden_channels, HEAD_HIDDEN)
+        self.linear2 = nn.Linear(HEAD_HIDDEN, output_dim)
+        self.relu = nn.ReLU()
+        self._graphs = _GraphCache()
+
+    def prepare_graph(self, edge_index, num_nodes: int) -> MeanOperator:
+        return prepare_mean_operator(edge_index, num_nodes)
+
+    def forward_prepared(self, x: torch.Tensor, op: MeanOperator):
+        _need_cuda(x)
+        n, f, t = x.shape
+        c = self.tgnn.out_channels
+        cell = self.tgnn._base_tgcn
+        xp = ops.pack_x(x)                                                        # (N, T, F)
+        ax = ops.spmm_csr(op.rowptr, op.col, op.val, xp.view(n, t * f))           # mean over in-neighbours: input data, no backward
+        a = torch.cat([ax.view(n * t, f), xp.view(n * t, f)], dim=1)              # [mean-neighbour x | x]  (M, 2F)
+        gs, cs = [], []
+        for conv, lin in ((cell.conv_z, cell.linear_z), (cell.conv_h, cell.linear_h)):
+            u1 = lin.weight[:, :c].contiguous()
+            gs.append(torch.cat([_compose(u1, conv.lin_l.weight), _compose(u1, conv.lin_r.weight)], dim=1))
+            cs.append(_compose_bias(u1, conv.lin_l.bias, lin.bias))
+        return self._run_cell0(a, a, gs[0], gs[1], cs[0], cs[1], n)
+
+    def forward(self, x, edge_index, edge_attr=None):
+        _need_cuda(x)
+        n = x.shape[0]
+        op = self._graphs.get([edge_index, None], n, lambda: prepare_mean_operator(edge_index, n))
+        return self.forward_prepared(x, op)
+
+
+class GATTemporal(_ZeroHiddenModel):
+    """GAT baseline (models/GATTemporal.py:7-34).  ``forward(x, edge_index, edge_attr)`` -> ``(prediction, hidden (N, 256))``;
+    ``edge_attr`` is accepted and ignored, as in the reference (:78-80)."""
+
+    cell_attr = "gat"
+    NEGATIVE_SLOPE = 0.2          # GATConv default
+
+    def __init__(self, node_features: int, num_nodes: int, periods: int, output_dim: int, hidden_channels: int = HIDDEN):
+        super().__init__()
+        self.gat = GAT(node_features, hidden_channels, num_nodes, periods)
+        self.output_dim = output_dim
+        self.linear1 = nn.Linear(hidden_channels, HEAD_HIDDEN)
+        self.linear2 = nn.Linear(HEAD_HIDDEN, output_dim)
+        self.relu = nn.ReLU()
+        self._graphs = _GraphCache()
+
+    def prepare_graph(self, edge_index, num_nodes: int) -> AttentionPattern:
+        return prepare_attention_pattern(edge_index, num_nodes)
+
+    def forward_prepared(self, x: torch.Tensor, pat: AttentionPattern):
+        _need_cuda(x)
+        n, f, t = x.shape
+        c = self.gat.out_channels
+        cell = self.gat._base_tgcn
+        xp = ops.pack_x(x)
+        ins, gs, cs = [], [], []
+        for conv, lin in ((cell.conv_z, cell.linear_z), (cell.conv_h, cell.linear_h)):
+            w = conv.lin.weight                                                    # (C, F)
+            u_src = LinearFunction.apply(conv.att_src.view(1, c), w.t().contiguous(), None).view(f)      # W^T att_src
+            u_dst = LinearFunction.apply(conv.att_dst.view(1, c), w.t().contiguous(), None).view(f)
+            ins.append(GatAggregateFunction.apply(xp, u_src, u_dst, pat, self.NEGATIVE_SLOPE).view(n * t, f))
+            u1 = lin.weight[:, :c].contiguous()
+            gs.append(_compose(u1, w))
+            cs.append(_compose_bias(u1, conv.bias, lin.bias))
+        return self._run_cell0(ins[0], ins[1], gs[0], gs[1], cs[0], cs[1], n)
+
+    def forward(self, x, edge_index, edge_attr=None):
+        _need_cuda(x)
+        n = x.shape[0]
+        pat = self._graphs.get([edge_index, None], n, lambda: prepare_attention_pattern(edge_index, n))
+        return self.forward_prepared(x, pat)

@@ -97,3 +97,26 @@ def mse_loss_grad(pred: torch.Tensor, y: torch.Tensor, global_count: Optional[in
     _lib.check(_lib.load().regt_mse_loss_grad(_lib.ptr(pred), _lib.ptr(y), _lib.ptr(dpred), _lib.ptr(loss), cnt,
                                               cnt if global_count is None else global_count, _stream()), "regt_mse_loss_grad")
     return loss, dpred
+
+
+def gat_forward(rowptr: torch.Tensor, col: torch.Tensor, xp: torch.Tensor, u_src: torch.Tensor, u_dst: torch.Tensor, slope: float = 0.2):
+    """GATConv attention aggregation on packed input rows xp (N,T,F): returns (out (N,T,F), stats (N*T,4))."""
+    xp, u_src, u_dst = _f32c(xp, "xp"), _f32c(u_src, "u_src"), _f32c(u_dst, "u_dst")
+    n, t, f = xp.shape
+    out = torch.empty_like(xp)
+    stats = torch.empty(n * t, 4, dtype=torch.float32, device=xp.device)
+    _lib.check(_lib.load().regt_gat_forward(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(xp), _lib.ptr(u_src), _lib.ptr(u_dst), slope,
+                                            n, t, f, _lib.ptr(out), _lib.ptr(stats), _stream()), "regt_gat_forward")
+    return out, stats
+
+
+def gat_backward(rowptr, col, t_rowptr, t_col, xp: torch.Tensor, u_src: torch.Tensor, dout: torch.Tensor, stats: torch.Tensor,
+                 slope: float = 0.2) -> torch.Tensor:
+    """Score gradients dsd (N*T, 2) = (dL/ds, dL/dd) of gat_forward given dL/dout (N,T,F)."""
+    xp, u_src, dout = _f32c(xp, "xp"), _f32c(u_src, "u_src"), _f32c(dout, "dout")
+    n, t, f = xp.shape
+    dsd = torch.empty(n * t, 2, dtype=torch.float32, device=xp.device)
+    _lib.check(_lib.load().regt_gat_backward(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(t_rowptr), _lib.ptr(t_col), _lib.ptr(xp),
+                                             _lib.ptr(u_src), slope, n, t, f, _lib.ptr(dout), _lib.ptr(stats), _lib.ptr(dsd), _stream()),
+               "regt_gat_backward")
+    return dsd

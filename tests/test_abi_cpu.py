@@ -91,3 +91,21 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     rc = lib.regt_wgrad(one, 4, one, 8, 16, 4, 8, one, 8, None, None, None)
     assert rc != 0 and b"bad argument" in lib.regt_last_error()
     assert lib.regt_set_gemm_mode(0) in (0, 1)
+
+
+def test_zero_hidden_models_keep_reference_layout():
+    """GraphSAGETemporalGCN / GATTemporal: state_dict keys in the order the reference's modules register them (the same
+    order oracle.init_params emits, which oracle/make_goldens.py asserts against the imported reference classes)."""
+    from oracle import model as M
+    for name, cls in (("GraphSAGETemporalGCN", R.GraphSAGETemporalGCN), ("GATTemporal", R.GATTemporal)):
+        m = cls(node_features=8, num_nodes=104, periods=6, output_dim=3)
+        p = M.init_params(name, 8, 6, 3, num_nodes=104, seed=0)
+        assert list(p.keys()) == list(m.state_dict().keys()), name
+        assert all(tuple(p[k].shape) == tuple(v.shape) for k, v in m.state_dict().items()), name
+        m.load_state_dict(p, strict=True)
+        import inspect
+        assert list(inspect.signature(m.forward).parameters) == ["x", "edge_index", "edge_attr"]
+        with pytest.raises(R.RegtError):
+            m(torch.zeros(104, 8, 6), torch.zeros(2, 0, dtype=torch.long), None)
+    with pytest.raises(NotImplementedError):
+        R.TGCN(8, 16, baseblock="transformer")

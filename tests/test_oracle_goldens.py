@@ -98,6 +98,36 @@ def test_conv_stacked_golden(tpims, tag):
         assert p[name].grad is None
 
 
+@pytest.mark.parametrize("name,short", [("GraphSAGETemporalGCN", "sage"), ("GATTemporal", "gat")])
+@pytest.mark.parametrize("tag", ["in6_out1", "in12_out3"])
+def test_zero_hidden_models_golden(tpims, name, short, tag):
+    """SURVEY 8(f) rank 4, second half: the oracle's GraphSAGE / GAT models against the reference modules' outputs."""
+    g = load_npz(f"golden_{short}_{tag}.npz")
+    t_in, t_out, w0 = int(g["t_in"]), int(g["t_out"]), int(g["window"])
+    n = tpims["node_data"].shape[0]
+    p0 = M.init_params(name, 8, t_in, t_out, num_nodes=n, seed=int(g["seed"]))
+    chk = float(sum(v.double().abs().sum() for v in p0.values()))
+    assert abs(chk - float(g["param_checksum"][0])) < 1e-6 * chk, "seeded parameter stream drifted"
+    p = _leaf(p0)
+    x = tpims["node_data"][:, :, w0:w0 + t_in].contiguous()
+    y = tpims["node_data"][:, -1, w0 + t_in:w0 + t_in + t_out].contiguous()
+    fwd = M.graphsage_temporal_gcn if short == "sage" else M.gat_temporal
+    pred, hidden = fwd(p, x, tpims["edge_index"], tpims["edge_attr"])
+    np.testing.assert_allclose(pred.detach().numpy(), g["pred"], atol=TOL)
+    np.testing.assert_allclose(hidden.detach().numpy(), g["hidden"], atol=TOL)
+    loss = torch.mean((pred - y) ** 2)
+    assert abs(float(loss.detach()) - float(g["loss"][0])) < 1e-6
+    loss.backward()
+    check_grads_against_golden(g, {k: v.grad for k, v in p.items()}, atol=2e-6)
+    pre = "tgnn." if short == "sage" else "gat."
+    # the reset gate multiplies the zero hidden state: its parameters receive an all-zero gradient (not None)
+    assert float(p[f"{pre}_base_tgcn.linear_r.weight"].grad.abs().max()) == 0.0
+    assert float(p[f"{pre}_base_tgcn.linear_z.weight"].grad[:, 256:].abs().max()) == 0.0     # H-half columns see H = 0
+    if short == "sage":
+        for k in M.UNUSED_PARAMS_SAGE:
+            assert p[k].grad is None
+
+
 def test_loop_golden(tpims):
     g = load_npz("golden_loop.npz")
     t_in, t_out = int(g["t_in"]), int(g["t_out"])

@@ -100,3 +100,41 @@ def test_conv_layers_compose():
     gcn = G.gcn_conv(x, ei, None, wl, b)
     want = G.dense_gcn_operator(ei, None, n) @ (x @ wl.t()) + b
     assert torch.allclose(gcn, want, atol=1e-12)
+
+
+# ---- SAGEConv / GATConv restatements (base blocks 'graphsage' / 'gat' of the TGCN cell) ----------------
+
+def test_sage_conv_is_mean_of_listed_in_edges():
+    # node 3 has a self loop (counted as a neighbour), edge 2->0 is listed twice (counted twice), node 6 has no in-edge (mean 0)
+    ei = torch.tensor([[0, 1, 2, 3, 3, 5, 2, 4, 4], [1, 2, 0, 3, 0, 2, 0, 1, 1]])
+    n, f, c = 7, 5, 6
+    x = torch.randn(n, f, dtype=torch.float64)
+    wl, wr = torch.randn(c, f, dtype=torch.float64), torch.randn(c, f, dtype=torch.float64)
+    bl = torch.randn(c, dtype=torch.float64)
+    got = G.sage_conv(x, ei, wl, bl, wr)
+    a = G.dense_mean_operator(ei, n)
+    assert torch.allclose(a[0], torch.tensor([0, 0, 2 / 3, 1 / 3, 0, 0, 0], dtype=torch.float64))       # 2->0 twice, 3->0 once
+    assert torch.allclose(a[3], torch.tensor([0, 0, 0, 1.0, 0, 0, 0], dtype=torch.float64))             # own loop only
+    assert float(a[6].abs().sum()) == 0.0
+    assert torch.allclose(got, (a @ x) @ wl.t() + bl + x @ wr.t(), atol=1e-12)
+
+
+def test_gat_conv_matches_dense_attention_formula():
+    ei = torch.tensor([[0, 1, 2, 3, 3, 5, 2, 4, 4], [1, 2, 0, 3, 0, 2, 0, 1, 1]])    # a self loop (dropped, re-added once) and a duplicate
+    n, f, c = 7, 5, 6
+    x = torch.randn(n, f, dtype=torch.float64)
+    w = torch.randn(c, f, dtype=torch.float64)
+    a_s, a_d = torch.randn(1, 1, c, dtype=torch.float64), torch.randn(1, 1, c, dtype=torch.float64)
+    b = torch.randn(c, dtype=torch.float64)
+    got = G.gat_conv(x, ei, w, a_s, a_d, b)
+    alpha = G.dense_gat_attention(x, ei, w, a_s, a_d)
+    assert torch.allclose(alpha.sum(dim=1), torch.ones(n, dtype=torch.float64))
+    assert float(alpha[6, 6]) == 1.0                       # a node without in-edges attends to itself only
+    assert torch.allclose(got, alpha @ (x @ w.t()) + b, atol=1e-12)
+    # hand-checkable two-node case: node 1 hears node 0 and itself
+    x2 = torch.tensor([[1.0], [2.0]], dtype=torch.float64)
+    one = torch.ones(1, 1, dtype=torch.float64)
+    out = G.gat_conv(x2, torch.tensor([[0], [1]]), one, one.view(1, 1, 1), one.view(1, 1, 1), torch.zeros(1, dtype=torch.float64))
+    e01, e11 = 1.0 + 2.0, 2.0 + 2.0                        # a_s[j] + a_d[i], positive -> leaky_relu is the identity
+    a01 = math.exp(e01) / (math.exp(e01) + math.exp(e11))
+    assert abs(float(out[1, 0]) - (a01 * 1.0 + (1 - a01) * 2.0)) < 1e-12 and abs(float(out[0, 0]) - 1.0) < 1e-12
