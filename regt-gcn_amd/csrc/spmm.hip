@@ -111,10 +111,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ r
 // (1.6 MB at cfg-3) and stays in L2, so each X line is fetched from HBM / MALL about once.
 // Eight lanes own one (row, panel): 8 x 16 B = one 128-B line per neighbour; the 8 lanes pull 8
 // (col, val) pairs with one coalesced load and broadcast them by shuffle, four gathers in flight.
+template <int PL>     // lanes per row = panel width in float4: 8 = one 128-B line per neighbour, 16 = two (half the CSR re-reads)
 __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const float* __restrict__ val, const float* __restrict__ X,
                                                          float* __restrict__ Y, int nnodes, int nstack, int W4,
                                                          int npanels, int nrb) {
+    constexpr int ROWS = 256 / PL;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
     const int per_panel = nstack * nrb;
     const int panel = li / per_panel;
@@ -124,26 +126,26 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
     const int q = nnodes / 8, r8 = nnodes % 8;
     const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     const int csz = q + (xcd < r8 ? 1 : 0);
-    const int g = threadIdx.x >> 3, gl = threadIdx.x & 7;
-    if (rb * 32 + g >= csz) return;                       // whole 8-lane group leaves together
-    const long row = (long)s * nnodes + c0 + rb * 32 + g;
-    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * 8 + gl;
+    const int g = threadIdx.x / PL, gl = threadIdx.x % PL;
+    if (rb * ROWS + g >= csz) return;                     // whole lane group leaves together
+    const long row = (long)s * nnodes + c0 + rb * ROWS + g;
+    const float4* X4 = reinterpret_cast<const float4*>(X) + panel * PL + gl;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int base = beg; base < end; base += 8) {
-        const int n = end - base < 8 ? end - base : 8;
+    for (int base = beg; base < end; base += PL) {
+        const int n = end - base < PL ? end - base : PL;
         int myc = 0;
         float myv = 0.f;
         if (gl < n) { myc = col[base + gl]; myv = val[base + gl]; }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < PL / 4; ++h) {
             if (h * 4 < n) {
                 float4 x[4];
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {               // lanes >= n carry (col 0, val 0): harmless
-                    const int c = __shfl(myc, h * 4 + e, 8);
-                    v[e] = __shfl(myv, h * 4 + e, 8);
+                    const int c = __shfl(myc, h * 4 + e, PL);
+                    v[e] = __shfl(myv, h * 4 + e, PL);
                     x[e] = X4[(long)c * W4];
                 }
 #pragma unroll
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
         }
     }
     // streaming stores: the output is not read again here and must not evict the XCD's slice of X from its L2
-    float4* py = reinterpret_cast<float4*>(Y) + row * W4 + panel * 8 + gl;
+    float4* py = reinterpret_cast<float4*>(Y) + row * W4 + panel * PL + gl;
     __builtin_nontemporal_store(acc.x, &py->x); __builtin_nontemporal_store(acc.y, &py->y);
     __builtin_nontemporal_store(acc.z, &py->z); __builtin_nontemporal_store(acc.w, &py->w);
 }
@@ -283,12 +285,22 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
     const int W4 = W / 4;
     // Panel variant when the X matrix cannot live in the XCDs' L2s anyway and rows are whole cache lines.
     if (W4 % 8 == 0 && (long)nrows_x * W * 4 > (24L << 20) && nrows / nstack >= 4096) {
-        const int nnodes = nrows / nstack, npanels = W4 / 8;
-        const int nrb = cdiv(cdiv(nnodes, 8), 32);
+        const int nnodes = nrows / nstack;
+        // 256-byte panels (half the passes over the CSR) while an XCD's slice of X (chunk x 256 B) stays around its 4 MiB L2
+        static int pl_env = -1;
+        if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
+        const bool wide = pl_env ? pl_env == 16 : (W4 % 16 == 0 && (long)cdiv(nnodes, 8) * 256 <= (7L << 19));
+        const int PL = wide ? 16 : 8;
+        const int npanels = W4 / PL;
+        const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
         const long grid = 8L * npanels * nstack * nrb;
         REGT_CHECK_ARG(grid < (1L << 31), "spmm: grid too large");
-        hipLaunchKernelGGL(spmm_panel_kernel, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, X, Y, nnodes, nstack, W4,
-                           npanels, nrb);
+        if (wide)
+            hipLaunchKernelGGL(spmm_panel_kernel<16>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, X, Y, nnodes, nstack, W4,
+                               npanels, nrb);
+        else
+            hipLaunchKernelGGL(spmm_panel_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val, X, Y, nnodes, nstack, W4,
+                               npanels, nrb);
         REGT_CHECK_LAUNCH();
         return REGT_OK;
     }

@@ -25,6 +25,10 @@ PARAM_NAMES_REGION = ["tgnn.linear.weight", "tgnn.linear.bias"]
 PARAM_NAMES_HEAD = ["linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias"]
 
 
+# parameters whose last dimension is the node-feature width F
+F_WIDE_PARAMS = tuple([f"tgnn._base_tgcn.conv_{k}.lin.weight" for k in GATES] + ["tgnn.conv.lins.0.weight", "tgnn.conv.lins.1.weight"])
+
+
 def param_names(regional: bool) -> List[str]:
     return PARAM_NAMES_COMMON + (PARAM_NAMES_REGION if regional else []) + PARAM_NAMES_HEAD
 
@@ -127,6 +131,15 @@ class RegTGCNFunction(torch.autograd.Function):
             if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
                 raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
         x = x.contiguous()
+        # The kernels read 16-byte feature rows (F a multiple of 4; the reference uses F = 8).  Any other width is staged
+        # padded: zero feature columns in x and zero weight columns for them change nothing in the forward, and their
+        # gradient columns (ds^T x_pad = 0) are sliced off in the backward.
+        f_real = x.shape[2] if packed else x.shape[1]
+        f_pad = (-f_real) % 4
+        if f_pad:
+            x = torch.nn.functional.pad(x, (0, f_pad) if packed else (0, 0, 0, f_pad)).contiguous()
+            params = tuple(torch.nn.functional.pad(p_, (0, f_pad)).contiguous() if n_ in F_WIDE_PARAMS else p_
+                           for n_, p_ in zip(names, params))
         if packed:
             x_rows, T, F = x.shape
             N = graph.num_nodes
@@ -173,6 +186,7 @@ class RegTGCNFunction(torch.autograd.Function):
         ctx.ps, ctx.gs = ps, gs                  # parameter / graph pointer structs: unchanged until backward
         ctx.xp = x if packed else None
         ctx.names = names
+        ctx.f_real, ctx.f_pad = f_real, f_pad
         ctx.save_for_backward(hidden, *params)
         return pred, hidden
 
@@ -197,6 +211,10 @@ class RegTGCNFunction(torch.autograd.Function):
         gr = _fill(_lib.Grads(), grads, regional)
         _lib.check(lib.regt_backward(C.byref(dims), C.byref(ctx.gs), C.byref(ctx.ps), C.byref(gr), _lib.ptr(dpred), _lib.ptr(dhid),
                                      _lib.ptr(hidden), _lib.ptr(ctx.xp), _lib.ptr(ctx.ws), ctx.wsb, _stream()), "regt_backward")
+        if ctx.f_pad:
+            for n_ in F_WIDE_PARAMS:
+                if n_ in grads:
+                    grads[n_] = grads[n_][:, :ctx.f_real].contiguous()
         return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
 
 

@@ -91,9 +91,10 @@ def test_spmm_matches_oracle(R, width):
     assert float((got.double() - want64).abs().max()) < 5e-6
 
 
-def test_spmm_panel_variant_large_graph(R):
-    """Large enough (X > 24 MB, width a multiple of 32) to take the XCD-aware column-panel kernel."""
-    n, e, width = 41003, 300000, 160
+@pytest.mark.parametrize("width", [160, 192])      # 160: 128-byte panels; 192 (a multiple of 64 floats): 256-byte panels
+def test_spmm_panel_variant_large_graph(R, width):
+    """Large enough (X > 24 MB, width a multiple of 32) to take the XCD-aware column-panel kernels."""
+    n, e = 41003, 300000
     ei, w = _rand_graph(n, e, 9)
     rp, col, val = R.graph.gcn_csr(ei.cuda(), w.cuda(), n)
     x = torch.randn(n, width, generator=torch.Generator().manual_seed(9))

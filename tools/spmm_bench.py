@@ -35,3 +35,20 @@ ms_cold = t_cold(dual)
 nnz = pg.m_col.numel()
 algo = nodes*W*4 + nnz*12 + (nodes+1)*4 + 2*nodes*W*4
 print(f"dual  PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}   cold: {ms_cold*1e3:7.1f} us")
+
+
+# ---- reference-faithful WIDE aggregation: a learned hidden state of width T*512 (ConvStackedTemporalGCN layers 2-5, models/
+# ConvStackedTemporalGCN.py:115-126), forward over A_hat and backward over A_hat^T.  Algorithmic bytes: read H once + CSR + write.
+if len(sys.argv) > 1 and sys.argv[1] == "wide":
+    Wd = 12 * 512
+    op = R.graph.prepare_gcn_operator(g.edge_index.to(dev), g.edge_attr.to(dev), nodes)
+    h = torch.rand(nodes, Wd, device=dev)
+    out = torch.empty_like(h)
+    for name, (rp, cl, vl) in (("A_hat  ", (op.rowptr, op.col, op.val)), ("A_hat^T", (op.t_rowptr, op.t_col, op.t_val))):
+        fn = lambda: _lib.check(lib.regt_spmm_csr(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(vl), _lib.ptr(h), _lib.ptr(out), nodes, nodes, Wd, st), "spmm")
+        ms = t(fn, 10)
+        nz = cl.numel()
+        algo = 2 * nodes * Wd * 4 + nz * 8 + (nodes + 1) * 4
+        print(f"wide {name} W={Wd} PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms:7.3f} ms  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e9:.2f} GB) = {algo/ms/1e6/8000:.3f} of 8 TB/s; "
+              f"gathered rows {nz*Wd*4/1e9:.1f} GB -> {nz*Wd*4/ms/1e6:.0f} GB/s through L2")
+    ref = torch.sparse_csr_tensor(op.rowptr.long(), op.col.long(), op.val, (nodes, nodes)) if False else None
