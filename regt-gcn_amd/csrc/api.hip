@@ -138,6 +138,27 @@ namespace {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// REGT_GEMM_MODE=bf16: the intermediates that only ever feed matrix-core operands -- q = h*R (forward -> backward), dhp and
+// dzp|drp (inside the backward) -- are STORED as bf16: their producer rounds them once instead of every consumer rounding
+// them while staging, which is the same arithmetic at half the HBM bytes for these buffers (7.5 of the step's ~37 row-units).
+// Needs the vector kernels everywhere (C a multiple of the 128-column tile, so that no GEMM falls back to the generic core).
+bool bf16_intermediates(const regt_dims& d) { return gemm_mode() == 2 && d.C % GBN == 0 && d.F % 4 == 0; }
+// q crosses from regt_forward to regt_backward: remember per workspace how the forward stored it, so that a mode change in
+// between is caught instead of misread.
+std::mutex g_qfmt_mu;
+std::unordered_map<const void*, int> g_qfmt;
+void note_q_format(const void* ws, int bf16) {
+    std::lock_guard<std::mutex> lk(g_qfmt_mu);
+    if (g_qfmt.size() > 4096) g_qfmt.clear();
+    g_qfmt[ws] = bf16;
+}
+int q_format(const void* ws) {
+    std::lock_guard<std::mutex> lk(g_qfmt_mu);
+    auto it = g_qfmt.find(ws);
+    return it == g_qfmt.end() ? 0 : it->second;
+}
+inline const float* byte_off(const float* p, long bytes) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + bytes); }
+
 GemmSeg make_seg(const float* A, long lda, const float* B0, const float* B1, long ldb, int nsplit, int K, bool bt,
                  int extra_flags = 0, long region_stride = 0) {
     GemmSeg s{};
@@ -337,6 +358,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* H = h_ext ? h_ext : L.h;
+    const int qbf = bf16_intermediates(d) ? 1 : 0;
     {
         PROF("compose_fwd", st);
         TRY(launch_softmax_small(p.attention, L.probs, T, st));
@@ -388,6 +410,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         S.row_div = T;
         EpiGates e{L.ZR, H, L.q, L.czr, C};
+        e.q_bf16 = qbf;
         PROF("gemm_gates", st);
         TRY(launch_gemm_gates(S, M, 2 * C, e, st));
     }
@@ -395,7 +418,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         CandArgs a{};
         a.S.nseg = 2;
-        a.S.seg[0] = make_seg(L.q, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, true);
+        a.S.seg[0] = make_seg(L.q, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, true, qbf ? SEG_A_BF16 : 0);
         a.S.seg[1] = make_seg(L.AX, F, L.Gh, nullptr, F, INT_MAX, F, true);
         a.S.row_div = T;
         a.num_nodes = N; a.T = T; a.C = C;
@@ -446,8 +469,9 @@ struct ReduceQueue {
 };
 
 int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu,
-               long M, int kchunk, int nchunks, float* out, long ldo, float* colsum, hipStream_t st) {
+               long M, int kchunk, int nchunks, float* out, long ldo, float* colsum, hipStream_t st, int p_bf16 = 0, int q_bf16 = 0) {
     WgradArgs a{P, ldp, Nout, Q, ldq, Nin, q_relu, M, kchunk, nullptr, nchunks, nullptr, colsum ? 1 : 0};
+    a.p_bf16 = p_bf16; a.q_bf16 = q_bf16;
     TRY(q.take((long)nchunks * wgrad_slab_stride(a), &a.slab));
     {
         PROF(name, st);
@@ -509,18 +533,20 @@ int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr
 // written to dh_ext and the embedding-stage gradients (A0 / A_r / Cheb weights) are skipped.
 int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
                   const float* dpred, const float* dhidden, const float* hidden, const float* xp_ext, const Layout& L,
-                  hipStream_t st, const float* h_ext = nullptr, float* dh_ext = nullptr) {
+                  hipStream_t st, int qbf, const float* h_ext = nullptr, float* dh_ext = nullptr) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* Xp = xp_ext ? xp_ext : L.Xp;
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
+    const int ibf = bf16_intermediates(d) ? 1 : 0;      // dhp, dzp|drp stored as bf16 (and q, by the forward: checked by the caller)
     // ---- head ----------------------------------------------------------------------------------
     ReduceQueue rq(L.slab, L.slab_floats, st);
     TRY(head_backward(d, p, gr, dpred, dhidden, hidden, L.y1, L.d1, L.dOH, L.kchunk_head, L.nchunks_head, rq, st));
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
+        a.out_bf16 = ibf;
         PROF("cell_bwd", st);
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
@@ -534,10 +560,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
         GemmSegs S{};
         S.nseg = 1;
-        if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true);
+        if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true, ibf ? SEG_A_BF16 : 0);
         else S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad1 e{H, L.ZR, L.dOH, L.probs, L.dzr, DH, C, T};
+        e.dzr_bf16 = ibf;
         PROF("dgrad_candidate", st);
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
     }
@@ -545,8 +572,9 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         GemmSegs S{};
         S.nseg = 2;
         if (split) {
-            S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true);
-            S.seg[1] = make_seg(L.dzr + C, 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true);
+            const int fl = ibf ? SEG_A_BF16 : 0;
+            S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true, fl);
+            S.seg[1] = make_seg(byte_off(L.dzr, (ibf ? 2L : 4L) * C), 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true, fl);
         } else {
             S.seg[0] = make_seg(L.dzr, 2L * C, p.gate_w[0] + C, nullptr, 2L * C, INT_MAX, C, false);
             S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);
@@ -557,10 +585,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
-    TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st));
-    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st));
+    TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
+    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st, ibf, 0));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        a.p_bf16 = ibf;
         TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Uzr", st);
@@ -575,7 +604,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(rq.push(r));
         }
     }
-    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st));
+    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st, ibf, 0));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
@@ -795,6 +824,7 @@ static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, co
     Layout L = make_layout(*dims, graph->n_chunks, graph->overlap, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     hipStream_t hs = (hipStream_t)st;
+    note_q_format(ws, bf16_intermediates(*dims) ? 1 : 0);
     if (!graphs_wanted((long)dims->N * dims->T))
         return forward_impl(*dims, *graph, *params, x, xp_ext, x_rows, pred, hidden, L, hs);
     // the snapshot changes every step: pack it with a plain launch, replay everything behind it
@@ -839,8 +869,11 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
     Layout L = make_layout(*dims, graph->n_chunks, graph->overlap, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     hipStream_t hs = (hipStream_t)st;
+    const int qbf = q_format(ws);
+    REGT_CHECK_ARG(qbf == (bf16_intermediates(*dims) ? 1 : 0),
+                   "regt_backward: the GEMM arithmetic changed since the forward on this workspace (regt_set_gemm_mode between forward and backward)");
     if (!graphs_wanted((long)dims->N * dims->T))
-        return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, hs);
+        return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, hs, qbf);
     unsigned long long key = hash_bytes(dims, sizeof(*dims), 0x84222325cbf29ce4ull);
     key = hash_bytes(graph, sizeof(*graph), key);
     key = hash_bytes(params, sizeof(*params), key);
@@ -849,7 +882,7 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
     key = hash_bytes(ptrs, sizeof(ptrs), key);
     const regt_dims dd = *dims; const regt_graph gg = *graph; const regt_params pp = *params; const regt_grads gr = *grads;
     return run_maybe_graphed(g_bwd_graphs, key, hs, [=](hipStream_t s) {
-        return backward_impl(dd, gg, pp, gr, dpred, dhidden, hidden, x_packed, L, s);
+        return backward_impl(dd, gg, pp, gr, dpred, dhidden, hidden, x_packed, L, s, qbf);
     });
 }
 
@@ -872,6 +905,7 @@ int32_t regt_cell_forward(const regt_dims* dims, const regt_graph* graph, const 
     REGT_CHECK_ARG(al16(x) && al16(h_in) && al16(hidden) && al16(ws), "regt_cell_forward: x, h_in, hidden and workspace must be 16-byte aligned");
     Layout L = make_layout(*dims, 0, 0, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
+    note_q_format(ws, bf16_intermediates(*dims) ? 1 : 0);
     return forward_impl(*dims, *graph, *params, x, nullptr, 0, pred, hidden, L, (hipStream_t)st, false, h_in);
 }
 
@@ -892,7 +926,10 @@ int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const
     }
     Layout L = make_layout(*dims, 0, 0, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
-    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, nullptr, L, (hipStream_t)st, h_in, dh_in);
+    const int qbf = q_format(ws);
+    REGT_CHECK_ARG(qbf == (bf16_intermediates(*dims) ? 1 : 0),
+                   "regt_cell_backward: the GEMM arithmetic changed since the forward on this workspace");
+    return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, nullptr, L, (hipStream_t)st, qbf, h_in, dh_in);
 }
 
 /* ---- zero-hidden cell (GraphSAGE / GAT models of the reference) ---------------------------------------------------------- */

@@ -28,6 +28,15 @@ int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st) 
 //   dzp = g (h - Ht) Z (1-Z)          (update-gate pre-activation gradient) -> dzr[:, 0:C]
 //   dp_t += <dOH[node], Z h + (1-Z) Ht>   (attention-probability gradient; fixed-order partial sums)
 constexpr int CB_MAXT = 64;
+// four fp32 -> four bf16 (round to nearest even), one 8-byte store at bf16 element index `elem`
+__device__ __forceinline__ void store_bf16x4(void* base, long elem, float4 v) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+    const bf16x2_t bl = __builtin_convertvector(lo, bf16x2_t), bh = __builtin_convertvector(hi, bf16x2_t);
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + 2 * elem) =
+        make_uint2(__builtin_bit_cast(unsigned, bl), __builtin_bit_cast(unsigned, bh));
+}
 __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
     __shared__ float dp[4][CB_MAXT];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -57,8 +66,13 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
     }
                 REGT_CB(x) REGT_CB(y) REGT_CB(z) REGT_CB(w)
 #undef REGT_CB
-                reinterpret_cast<float4*>(a.dhp + m * C)[c4] = dhp;
-                reinterpret_cast<float4*>(a.dzr + m * lddz)[c4] = dzp;
+                if (a.out_bf16) {      // GEMM-only intermediates, rounded once here (REGT_GEMM_MODE=bf16)
+                    store_bf16x4(a.dhp, m * C + 4 * c4, dhp);
+                    store_bf16x4(a.dzr, m * lddz + 4 * c4, dzp);
+                } else {
+                    reinterpret_cast<float4*>(a.dhp + m * C)[c4] = dhp;
+                    reinterpret_cast<float4*>(a.dzr + m * lddz)[c4] = dzp;
+                }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);

@@ -33,6 +33,20 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// four fp32 -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32), one 8-byte store; `p` addresses bf16 elements
+__device__ __forceinline__ void st4_bf16(void* base, long elem, float4 v) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+    const bf16x2_t bl = __builtin_convertvector(lo, bf16x2_t), bh = __builtin_convertvector(hi, bf16x2_t);
+    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + 2 * elem) =
+        make_uint2(__builtin_bit_cast(unsigned, bl), __builtin_bit_cast(unsigned, bh));
+}
+// 4 bf16 (8 bytes) widened to fp32 bit patterns
+__device__ __forceinline__ float4 widen_bf16x4(unsigned lo, unsigned hi) {
+    return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                       __uint_as_float(hi & 0xffff0000u));
+}
 #define REGT_V4(expr_x) make_float4(expr_x(x), expr_x(y), expr_x(z), expr_x(w))
 
 struct EpiBiasActF {
@@ -48,6 +62,7 @@ struct EpiBiasActF {
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
         e.out[m * e.ldo + c] = act(v + (e.bias ? e.bias[c] : 0.f));
     }
+    static constexpr int ROUND_ROWS = 16;
     struct Aux { float4 b; };
     __device__ __forceinline__ Aux load(long, int c) const { return Aux{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
     __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
@@ -61,8 +76,9 @@ struct EpiGatesF {
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
         float g = fast_sigmoid(v + e.bias[c]);
         e.ZR[m * (2L * e.C) + c] = g;
-        if (c >= e.C) e.q[m * e.C + c - e.C] = e.h[m * e.C + c - e.C] * g;
+        if (c >= e.C) e.q[m * e.C + c - e.C] = e.h[m * e.C + c - e.C] * g;      // fp32 storage only (vector path handles bf16)
     }
+    static constexpr int ROUND_ROWS = 16;
     struct Aux { float4 b, h; };
     __device__ __forceinline__ Aux load(long m, int c) const {
         Aux a;
@@ -75,7 +91,11 @@ struct EpiGatesF {
         const float4 g = REGT_V4(F_);
 #undef F_
         st4(e.ZR + m * (2L * e.C) + c, g);
-        if (c >= e.C) st4(e.q + m * e.C + c - e.C, make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w));
+        if (c >= e.C) {
+            const float4 qv = make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w);
+            if (e.q_bf16) st4_bf16(e.q, m * e.C + c - e.C, qv);
+            else st4(e.q + m * e.C + c - e.C, qv);
+        }
     }
 };
 struct EpiDgrad1F {
@@ -89,6 +109,7 @@ struct EpiDgrad1F {
         e.dzr[m * (2L * e.C) + e.C + c] = v * hv * (R * (1.0f - R));
         e.dh[m * e.C + c] = v * R + e.probs[t] * e.dOH[node * e.C + c] * Z;
     }
+    static constexpr int ROUND_ROWS = 8;
     struct Aux { float4 h, Z, R, d; float p; };
     __device__ __forceinline__ Aux load(long m, int c) const {
         const long node = m / e.T;
@@ -102,7 +123,8 @@ struct EpiDgrad1F {
     }
     __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
 #define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
-        st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
+        if (e.dzr_bf16) st4_bf16(e.dzr, m * (2L * e.C) + e.C + c, REGT_V4(F_));
+        else st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
 #undef F_
 #define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
         st4(e.dh + m * e.C + c, REGT_V4(F_));
@@ -117,6 +139,7 @@ struct EpiDgrad2F {
         if (e.act == ACT_LRELU) d = e.h[i] > 0.f ? d : d * e.slope;
         e.dh[i] = d;
     }
+    static constexpr int ROUND_ROWS = 16;
     struct Aux { float4 d, h; };
     __device__ __forceinline__ Aux load(long m, int c) const {
         Aux a;
@@ -137,6 +160,7 @@ struct EpiMaskAddF {
         if (e.add) o += e.add[m * e.ldadd + c];
         e.out[m * e.ldo + c] = o;
     }
+    static constexpr int ROUND_ROWS = 16;
     struct Aux { float4 mk, ad; };
     __device__ __forceinline__ Aux load(long m, int c) const {
         Aux a;
@@ -259,6 +283,9 @@ static int fast_class(const GemmSegs& S, int N, bool vec) {
     for (int s = 0; s < S.nseg; ++s) {
         const GemmSeg& g = S.seg[s];
         if (!(g.flags & SEG_VEC_A) || !(g.flags & SEG_VEC_B) || g.K % 4 != 0) return -1;
+        // only the bf16-operand core reads bf16 rows: 16-byte loads of 8 k, never region-masked
+        if ((g.flags & SEG_A_BF16) && (gemm_mode() != 2 || !(g.flags & SEG_BT) || g.K % 8 != 0 || g.lda % 8 != 0 ||
+                                       (g.flags & (SEG_REGION | SEG_REPEAT | SEG_RELU_A)))) return -1;
         const int b = (g.flags & SEG_BT) ? 1 : 0;
         if (bt >= 0 && bt != b) return -1;
         bt = b;
@@ -325,6 +352,8 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
 template <class EpiF>
 static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, bool vec, hipStream_t st) {
     REGT_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%ld N=%d", M, N);
+    for (int q = 0; q < S.nseg; ++q)
+        REGT_CHECK_ARG(!(S.seg[q].flags & SEG_A_BF16), "gemm: a bf16-stored operand needs the bf16-operand vector path");
     long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
     static bool attr_done = false;
@@ -349,12 +378,14 @@ int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipSt
     REGT_CHECK_ARG(N == 2 * e.C, "gates gemm expects N == 2C");
     const bool vec = e.C % 4 == 0 && a16(e.ZR) && a16(e.h) && a16(e.q) && a16(e.bias);
     if (fast_class(S, N, vec) == 1) return launch_fast<EpiGatesF, true, false>(S, M, N, EpiGatesF{e}, 0, st);
+    REGT_CHECK_ARG(!e.q_bf16, "gates gemm: bf16 storage of q needs the vector path");
     return launch_flat(S, M, N, EpiGatesF{e}, vec, st);
 }
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh);
     if (fast_class(S, N, vec) == 1) return launch_fast<EpiDgrad1F, true, false>(S, M, N, EpiDgrad1F{e}, 0, st);
+    REGT_CHECK_ARG(!e.dzr_bf16, "dgrad1 gemm: bf16 storage of dzr needs the bf16-operand vector path");
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad1F, false, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad1F{e}, vec, st);
 }
@@ -439,29 +470,44 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     typename Core::Acc acc;
     Core::zero(acc);
     core.run(acc, false);
-    core.stage(acc);
     const int c = core.ecol();
     const int node0 = (int)(m0 / a.T);
+    // epilogue rows in rounds of RR; the first round's Z / h rows are requested before the accumulators are staged through
+    // LDS (their HBM latency overlaps the staging), see FastCore::for_each_vec
+    constexpr int RR = Core::EROWS >= 8 ? 8 : Core::EROWS;
+    float4 Z[RR], hv[RR];
+    if (c < a.C) {
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int r = core.erow(j);
+            if (r < rm.nvalid) {
+                Z[j] = ld4(a.ZR + (m0 + r) * 2 * C + c);
+                hv[j] = ld4(a.h + (m0 + r) * C + c);
+            }
+        }
+    }
+    core.stage(acc);
     if (c < a.C) {
         const float4 b = ld4(a.bias + c);
 #pragma unroll
-        for (int g = 0; g < Core::EROWS / 4; ++g) {
-            float4 Z[4], hv[4];
+        for (int g = 0; g < Core::EROWS / RR; ++g) {
+            if (g > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = core.erow(4 * g + j);
-                if (r < rm.nvalid) {
-                    Z[j] = ld4(a.ZR + (m0 + r) * 2 * C + c);
-                    hv[j] = ld4(a.h + (m0 + r) * C + c);
+                for (int j = 0; j < RR; ++j) {
+                    const int r = core.erow(RR * g + j);
+                    if (r < rm.nvalid) {
+                        Z[j] = ld4(a.ZR + (m0 + r) * 2 * C + c);
+                        hv[j] = ld4(a.h + (m0 + r) * C + c);
+                    }
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = core.erow(4 * g + j);
+            for (int j = 0; j < RR; ++j) {
+                const int r = core.erow(RR * g + j);
                 if (r < rm.nvalid) {
                     const long m = m0 + r;
                     const float pt = a.probs[(int)(m % a.T)];
-                    const float4 v = core.eread(4 * g + j);
+                    const float4 v = core.eread(RR * g + j);
 #define F_(k) fast_tanh(v.k + b.k)
                     const float4 ht = REGT_V4(F_);
 #undef F_
@@ -521,6 +567,8 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         else
             hipLaunchKernelGGL((gemm_cand_flat_kernel<FastCore<true, false>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
     } else {
+        for (int q = 0; q < a.S.nseg; ++q)
+            REGT_CHECK_ARG(!(a.S.seg[q].flags & SEG_A_BF16), "candidate gemm: a bf16-stored operand needs the bf16-operand vector path");
         static bool attr_done2 = false;
         if (int rc = set_lds_once(&gemm_cand_kernel, G_LDS_BYTES, &attr_done2)) return rc;
         hipLaunchKernelGGL(gemm_cand_kernel, dim3((unsigned)tiles), dim3(256), G_LDS_BYTES, st, a);
@@ -535,7 +583,7 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
 constexpr int W_BK = 32;
 constexpr int W_LDP = 128 + 4;
 
-template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
+template <int BNW, bool PBF = false>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 128 ? 2 : 1;
     constexpr int LDQ = BNW + 4;
@@ -581,18 +629,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 
     // Both operands stream through wave-uniform buffer descriptors based at the chunk's first row
     // (vector path: ldp/ldq multiples of 4 and 16-B aligned bases, checked on the host).
-    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(a.P + r0 * a.ldp + i0);
+    // PBF: P holds bf16 elements (REGT_GEMM_MODE=bf16: dhp, dzp|drp are rounded once by their producer): a 32 x 128 slab is
+    // 8 KB = two 16-byte loads per thread (8 columns each), widened to fp32 on the way into LDS -- this kernel's arithmetic
+    // stays the fp32 MFMA
     const bool second = a.Q2 != nullptr && j0 >= a.nin_split;          // this column tile reads the second operand
+    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(a.P) + (PBF ? 2 : 4) * (r0 * a.ldp + i0)));
     const __amdgpu_buffer_rsrc_t sq = second ? Core::make_srd(a.Q2 + r0 * a.ldq2 + (j0 - a.nin_split)) : Core::make_srd(a.Q + r0 * a.ldq + j0);
     const int ldp = (int)a.ldp, ldq = second ? (int)a.ldq2 : (int)a.ldq;
 
     auto load = [&](int k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
+        if (PBF) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int slot = tid + 256 * s;
-            const int m = k0 + (slot >> 5), i = 4 * (slot & 31);
-            const bool ok = m < nrows && i0 + i < a.Nout;
-            rp[s] = Core::srd_load(sp, ok ? 4u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
+            for (int s = 0; s < 2; ++s) {
+                const int idx = tid + 256 * s;
+                const int m = k0 + (idx >> 4), i = 8 * (idx & 15);
+                const bool ok = m < nrows && i0 + i < a.Nout;
+                const float4 raw = Core::srd_load(sp, ok ? 2u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
+                rp[2 * s] = widen_bf16x4(__float_as_uint(raw.x), __float_as_uint(raw.y));
+                rp[2 * s + 1] = widen_bf16x4(__float_as_uint(raw.z), __float_as_uint(raw.w));
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int slot = tid + 256 * s;
+                const int m = k0 + (slot >> 5), i = 4 * (slot & 31);
+                const bool ok = m < nrows && i0 + i < a.Nout;
+                rp[s] = Core::srd_load(sp, ok ? 4u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
+            }
         }
 #pragma unroll
         for (int s = 0; s < QSLOTS; ++s) {
@@ -605,10 +669,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     auto store = [&](int stage, const float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
         float* lp = lds + stage * (P_TILE + Q_TILE);
         float* lq = lp + P_TILE;
+        if (PBF) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            int slot = tid + 256 * s;
-            *reinterpret_cast<float4*>(lp + (slot >> 5) * W_LDP + 4 * (slot & 31)) = rp[s];
+            for (int s = 0; s < 2; ++s) {
+                const int idx = tid + 256 * s;
+                float* d = lp + (idx >> 4) * W_LDP + 8 * (idx & 15);
+                *reinterpret_cast<float4*>(d) = rp[2 * s];
+                *reinterpret_cast<float4*>(d + 4) = rp[2 * s + 1];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                int slot = tid + 256 * s;
+                *reinterpret_cast<float4*>(lp + (slot >> 5) * W_LDP + 4 * (slot & 31)) = rp[s];
+            }
         }
 #pragma unroll
         for (int s = 0; s < QSLOTS; ++s) {
@@ -720,8 +794,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 constexpr int WS_PLANE_B = 16 * 256;             // one plane of one operand of one half slab
 __device__ __forceinline__ int ws_off(int m, int ch) { return 256 * m + 16 * (ch ^ (((m & 3) << 2) | ((m >> 2) & 3))); }
 
-template <int NP>   // 3: exact 3-way split, six partial products; 1: plain bf16 operands, one product (REGT_GEMM_MODE=bf16)
+// PBF / QBF (NP = 1 only): the operand is STORED as bf16 (dhp, dzp|drp, q: rounded once by their producers).  A half slab
+// of such an operand is 16 rows x 128 columns x 2 B = 4 KB = one 16-byte load per thread (row tid >> 4, columns 8 (tid & 15)
+// ..+7) that goes to LDS as it is: the chunk layout of ws_off already is 8 bf16 per 16 bytes.
+template <int NP, bool PBF = false, bool QBF = false>   // NP 3: exact 3-way split; 1: plain bf16 operands (REGT_GEMM_MODE=bf16)
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
+    static_assert(NP == 1 || (!PBF && !QBF), "bf16-stored operands only with the plain bf16 arithmetic");
     constexpr int WS_OPER_B = NP * WS_PLANE_B;       // 12288 / 4096
     constexpr int WS_STAGE_B = 2 * WS_OPER_B;        // P planes, then Q planes
     constexpr int WS_RED_B = 256 * 16;               // column-sum reduction image
@@ -764,36 +842,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);      // column sums of the thread's 4 columns of P over its rows
+    float4 csum2 = make_float4(0.f, 0.f, 0.f, 0.f);     // PBF: the thread owns 8 columns (csum: 0-3, csum2: 4-7)
     const bool do_csum = a.colsum && j0 == 0;
 
-    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(a.P + r0 * a.ldp + i0);
-    const __amdgpu_buffer_rsrc_t sq = Core::make_srd(a.Q + r0 * a.ldq + j0);
+    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(a.P) + (PBF ? 2 : 4) * (r0 * a.ldp + i0)));
+    const __amdgpu_buffer_rsrc_t sq = Core::make_srd(reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(a.Q) + (QBF ? 2 : 4) * (r0 * a.ldq + j0)));
     const int ldp = (int)a.ldp, ldq = (int)a.ldq;
-    const int c4 = tid & 31;                             // the thread's float4 column (4 i's) in both tiles
-    const bool okp = i0 + 4 * c4 < a.Nout, okq = j0 + 4 * c4 < a.Nin;
+    const int c4 = tid & 31;                             // fp32 operand: the thread's float4 column (4 i's)
+    const int c8 = tid & 15;                             // bf16 operand: the thread's 16-byte chunk (8 i's)
+    const bool okp = PBF ? i0 + 8 * c8 < a.Nout : i0 + 4 * c4 < a.Nout;
+    const bool okq = QBF ? j0 + 8 * c8 < a.Nin : j0 + 4 * c4 < a.Nin;
     const float qfloor = a.q_relu ? 0.f : -__builtin_inff();
 
-    // slot s of a thread: half h = s & 1, row 16 h + (tid >> 5) + 8 (s >> 1) of the 32-row slab
+    // fp32 operand: slot s of a thread: half h = s & 1, row 16 h + (tid >> 5) + 8 (s >> 1) of the 32-row slab (registers
+    // h and h + 2); bf16 operand: register h holds the 16 raw bytes of row 16 h + (tid >> 4)
     auto load_half = [&](int h, int k0, bool live, float4 (&rp)[4], float4 (&rq)[4]) {
+        if (PBF) {
+            const int m = k0 + 16 * h + (tid >> 4);
+            rp[h] = Core::srd_load(sp, live && m < nrows && okp ? 2u * (unsigned)(m * ldp + 8 * c8) : Core::SRD_OOB);
+        }
+        if (QBF) {
+            const int m = k0 + 16 * h + (tid >> 4);
+            rq[h] = Core::srd_load(sq, live && m < nrows && okq ? 2u * (unsigned)(m * ldq + 8 * c8) : Core::SRD_OOB);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = k0 + 16 * h + (tid >> 5) + 8 * j;
             const bool ok = live && m < nrows;
-            rp[h + 2 * j] = Core::srd_load(sp, ok && okp ? 4u * (unsigned)(m * ldp + 4 * c4) : Core::SRD_OOB);
-            rq[h + 2 * j] = Core::srd_load(sq, ok && okq ? 4u * (unsigned)(m * ldq + 4 * c4) : Core::SRD_OOB);
+            if (!PBF) rp[h + 2 * j] = Core::srd_load(sp, ok && okp ? 4u * (unsigned)(m * ldp + 4 * c4) : Core::SRD_OOB);
+            if (!QBF) rq[h + 2 * j] = Core::srd_load(sq, ok && okq ? 4u * (unsigned)(m * ldq + 4 * c4) : Core::SRD_OOB);
         }
     };
     auto store_half = [&](int h, const float4 (&rp)[4], const float4 (&rq)[4]) {
         char* st = ldsb + h * WS_STAGE_B;
+        if (PBF) {
+            const float4 raw = rp[h];
+            *reinterpret_cast<float4*>(st + ws_off(tid >> 4, c8)) = raw;
+            const float4 lo = widen_bf16x4(__float_as_uint(raw.x), __float_as_uint(raw.y));
+            const float4 hi = widen_bf16x4(__float_as_uint(raw.z), __float_as_uint(raw.w));
+            csum.x += lo.x; csum.y += lo.y; csum.z += lo.z; csum.w += lo.w;
+            csum2.x += hi.x; csum2.y += hi.y; csum2.z += hi.z; csum2.w += hi.w;
+        }
+        if (QBF) *reinterpret_cast<float4*>(st + WS_OPER_B + ws_off(tid >> 4, c8)) = rq[h];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const float4 p = rp[h + 2 * j];
-            float4 q = rq[h + 2 * j];
-            q.x = fmaxf(q.x, qfloor); q.y = fmaxf(q.y, qfloor); q.z = fmaxf(q.z, qfloor); q.w = fmaxf(q.w, qfloor);
-            csum.x += p.x; csum.y += p.y; csum.z += p.z; csum.w += p.w;
             const int off = ws_off((tid >> 5) + 8 * j, c4 >> 1) + 8 * (c4 & 1);
-            SplitCore<false, NP>::split_store(st + off, p, WS_PLANE_B);
-            SplitCore<false, NP>::split_store(st + WS_OPER_B + off, q, WS_PLANE_B);
+            if (!PBF) {
+                const float4 p = rp[h + 2 * j];
+                csum.x += p.x; csum.y += p.y; csum.z += p.z; csum.w += p.w;
+                SplitCore<false, NP>::split_store(st + off, p, WS_PLANE_B);
+            }
+            if (!QBF) {
+                float4 q = rq[h + 2 * j];
+                q.x = fmaxf(q.x, qfloor); q.y = fmaxf(q.y, qfloor); q.z = fmaxf(q.z, qfloor); q.w = fmaxf(q.w, qfloor);
+                SplitCore<false, NP>::split_store(st + WS_OPER_B + off, q, WS_PLANE_B);
+            }
         }
     };
     struct Frags { bf16x8 a[2][NP], b[2][NP]; };
@@ -897,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
                 }
             }
         }
-    if (do_csum) {      // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fixed-order reduction through LDS
+    if (do_csum && !PBF) {      // 8 threads (tid >> 5) hold partial sums of the same 4 columns: fixed-order reduction through LDS
         __syncthreads();
         reinterpret_cast<float4*>(lds)[tid] = csum;
         __syncthreads();
@@ -905,6 +1010,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) s += lds[(g * 32 + (tid >> 2)) * 4 + (tid & 3)];
+            out[(long)a.Nout * a.Nin + i0 + tid] = s;
+        }
+    }
+    if (do_csum && PBF) {       // 16 threads (tid >> 4) hold partial sums of the same 8 columns
+        __syncthreads();
+        reinterpret_cast<float4*>(lds)[2 * tid] = csum;
+        reinterpret_cast<float4*>(lds)[2 * tid + 1] = csum2;
+        __syncthreads();
+        if (tid < 128 && i0 + tid < a.Nout) {
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += lds[(g * 16 + (tid >> 3)) * 8 + (tid & 7)];
             out[(long)a.Nout * a.Nin + i0 + tid] = s;
         }
     }
@@ -1042,15 +1159,22 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
                       a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536) &&
                       (!a.Q2 || (a.ldq2 % 4 == 0 && a.ldq2 < (1L << 20) && a16(a.Q2) && a.nin_split % 32 == 0));
     REGT_CHECK_ARG(!a.Q2 || fast, "wgrad: a second right-hand operand needs 16-byte tileable operands and nin_split %% 32 == 0");
+    REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16) || fast, "wgrad: bf16 operands need the vector kernels");
     if (wide) {
-        static bool attr_done = false, attr_done_g = false, attr_done_s = false, attr_done_b = false;
+        static bool attr_done = false, attr_done_g = false, attr_done_s = false;
         if (fast && gemm_mode() == 1) {
             if (int rc = set_lds_once(&wgrad_split_kernel<3>, 4 * 3 * WS_PLANE_B, &attr_done_s)) return rc;
             hipLaunchKernelGGL(wgrad_split_kernel<3>, dim3((unsigned)blocks), dim3(256), 4 * 3 * WS_PLANE_B, st, a);
         } else if (fast && gemm_mode() == 2) {
-            if (int rc = set_lds_once(&wgrad_split_kernel<1>, 4 * 1 * WS_PLANE_B, &attr_done_b)) return rc;
-            hipLaunchKernelGGL(wgrad_split_kernel<1>, dim3((unsigned)blocks), dim3(256), 4 * 1 * WS_PLANE_B, st, a);
+            REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16) || (a.Nout % 8 == 0 && a.Nin % 8 == 0 && a.ldp % 8 == 0 && a.ldq % 8 == 0 && !a.q_relu),
+                           "wgrad: bf16-stored operands need 8-element aligned rows");
+            const size_t lb = 4 * 1 * WS_PLANE_B;
+            if (a.p_bf16 && a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
+            else if (a.p_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);
+            else if (a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
+            else hipLaunchKernelGGL((wgrad_split_kernel<1, false, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);
         } else if (fast) {
+            REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16), "wgrad: bf16-stored operands with the fp32 wide kernel");
             if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
             hipLaunchKernelGGL(wgrad_kernel<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
         } else {
@@ -1058,7 +1182,9 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
             hipLaunchKernelGGL(wgrad_kernel_generic<128>, dim3((unsigned)blocks), dim3(256), lds, st, a);
         }
     } else if (fast) {
-        hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+        REGT_CHECK_ARG(!a.q_bf16 && (!a.p_bf16 || (a.Nout % 8 == 0 && a.ldp % 8 == 0)), "wgrad: skinny kernel takes a bf16-stored P only");
+        if (a.p_bf16) hipLaunchKernelGGL((wgrad_kernel<32, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     } else {
         hipLaunchKernelGGL(wgrad_kernel_generic<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     }

@@ -31,6 +31,8 @@ enum : int {
     SEG_REGION = 4,   // region-masked segment (see header comment)
     SEG_VEC_A = 8,    // A rows may be read as aligned float4
     SEG_VEC_B = 16,   // B rows may be read as aligned float4
+    SEG_A_BF16 = 64,  // A holds bf16 elements (lda in elements); bf16-operand core only (REGT_GEMM_MODE=bf16): the GEMM-only
+                      // intermediates q, dhp, dzp|drp are rounded once by their producer instead of by every consumer
     SEG_REPEAT = 32,  // unmasked repeat: rep r = 0..nrep-1 uses A + r*a_rep_stride and B + r*b_region_stride
                       // (overlapping regional graphs: one (L~_r x) operand and one composed weight per region)
 };

@@ -23,6 +23,7 @@ struct ItDesc {
     const float* B1;
     long lda, ldb;
     int K, k0, region, nsplit;
+    int abf, pad_;        // A operand stored as bf16 (SEG_A_BF16)
 };
 constexpr int G_TABLE_BYTES = G_MAX_ITERS * (int)sizeof(ItDesc);
 constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
@@ -145,7 +146,7 @@ struct FastCore {
                         const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
                         d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
                         d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
-                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
+                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit; d.abf = (g.flags & SEG_A_BF16) ? 1 : 0; d.pad_ = 0;
                         table[n++] = d;
                     }
                 }
@@ -174,15 +175,18 @@ struct FastCore {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    struct Srds { __amdgpu_buffer_rsrc_t a, b; int lda, ldb, K, k0, region; };
+    struct Srds { __amdgpu_buffer_rsrc_t a, b; int lda, ldb, K, k0, region, abf; };
     __device__ __forceinline__ Srds make_srds(const ItDesc& d) const {
         Srds r;
+        r.abf = __builtin_amdgcn_readfirstlane(d.abf);
         r.lda = __builtin_amdgcn_readfirstlane((int)d.lda);
         r.ldb = __builtin_amdgcn_readfirstlane((int)d.ldb);
         r.K = __builtin_amdgcn_readfirstlane(d.K);
         r.k0 = __builtin_amdgcn_readfirstlane(d.k0);
         r.region = __builtin_amdgcn_readfirstlane(d.region);
-        r.a = make_srd(d.A + rm.base * d.lda);
+        // byte address of the tile's first A row: bf16 rows are half as long
+        r.a = make_srd(r.abf ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(d.A) + 2 * rm.base * d.lda)
+                             : d.A + rm.base * d.lda);
         const int ns = __builtin_amdgcn_readfirstlane(d.nsplit);
         if (BT) r.b = make_srd(n0 < ns ? d.B0 + (long)n0 * d.ldb : d.B1 + (long)(n0 - ns) * d.ldb);
         else r.b = make_srd(d.B0 + n0);
@@ -324,23 +328,39 @@ struct FastCore {
     __device__ __forceinline__ float4 eread(int i) const {
         return *reinterpret_cast<const float4*>(lds + erow(i) * G_LDS_KROW + 4 * (tid & 31));
     }
+    // Epilogue driver.  The auxiliary operands (h, Z, R, ... rows of this tile) come from HBM: every round of loads exposes
+    // one memory latency (2-4k cycles under load) to a wave that has nothing else to do, so the rows are handled in as few
+    // rounds as the functor's operand count allows (F::ROUND_ROWS of the thread's 16 rows per round: 16 for one float4 per
+    // row, 8 for two to four), and the first round is requested BEFORE the accumulators are staged through LDS, so that
+    // its latency overlaps the 64 LDS writes and the barrier.
     template <class F>
     __device__ __forceinline__ void for_each_vec(f32x16 (&acc)[2][2], const F& f) const {
-        stage(acc);
+        constexpr int RR = F::ROUND_ROWS;
+        static_assert(RR == 4 || RR == 8 || RR == 16, "rows per epilogue round");
         const int c = ecol();
+        typename F::Aux aux[RR];
         if (c < N) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                typename F::Aux aux[4];
+            for (int j = 0; j < RR; ++j) {
+                const int r = erow(j);
+                if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+            }
+        }
+        stage(acc);
+        if (c < N) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = erow(4 * g + j);
-                    if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+            for (int g = 0; g < 16 / RR; ++g) {
+                if (g > 0) {
+#pragma unroll
+                    for (int j = 0; j < RR; ++j) {
+                        const int r = erow(RR * g + j);
+                        if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = erow(4 * g + j);
-                    if (r < rm.nvalid) f.apply(rm.grow(r), c, eread(4 * g + j), aux[j]);
+                for (int j = 0; j < RR; ++j) {
+                    const int r = erow(RR * g + j);
+                    if (r < rm.nvalid) f.apply(rm.grow(r), c, eread(RR * g + j), aux[j]);
                 }
             }
         }

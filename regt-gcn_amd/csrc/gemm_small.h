@@ -71,7 +71,7 @@ struct SmallCore {
                         const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
                         d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
                         d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
-                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit;
+                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit; d.abf = 0; d.pad_ = 0;
                         table[n++] = d;
                     }
                 }

@@ -117,15 +117,20 @@ struct SplitCore : FastCore<true, REGION> {
         }
     }
     // store the thread's slots of half h (slots h and h+2) of one register set
+    // `abf` (wave-uniform): ra[h] holds 16 raw bytes = the 8 bf16 of k-group (tid & 1) of row tid >> 1, loaded from an
+    // operand its producer already rounded to bf16 (SEG_A_BF16): they go to LDS as they are, one ds_write_b128, no VALU
     template <bool RELU>
-    __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4]) const {
+    __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4], int abf = 0) const {
         char* st = reinterpret_cast<char*>(lds) + h * STAGE_B;
+        if (NP == 1 && abf) *reinterpret_cast<float4*>(st + sp_off(tid >> 1, tid & 1)) = ra[h];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float4 a = ra[h + 2 * j];
-            if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             const int off = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
-            split_store(st + off, a);
+            if (!(NP == 1 && abf)) {
+                float4 a = ra[h + 2 * j];
+                if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                split_store(st + off, a);
+            }
             split_store(st + OPER_B + off, rb[h + 2 * j]);
         }
     }
@@ -137,8 +142,16 @@ struct SplitCore : FastCore<true, REGION> {
         return d;
     }
     __device__ __forceinline__ void load_half(int h, const Srds& d, float4 (&ra)[4], float4 (&rb)[4]) const {
+        if (NP == 1 && d.abf) {      // bf16 rows: ONE 16-byte load per thread = 8 k of row tid >> 1 (128 rows x 2 k-groups)
+            const int rl = tid >> 1, k = d.k0 + 16 * h + 8 * (tid & 1);
+            const bool ok = rl < rm.nvalid && k < d.K;
+            ra[h] = Base::srd_load(d.a, ok ? 2u * (unsigned)(rl * (int)rm.mul * d.lda + k) : Base::SRD_OOB);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { ra[h + 2 * j] = sload_a(d, h + 2 * j); rb[h + 2 * j] = sload_b(d, h + 2 * j); }
+            for (int j = 0; j < 2; ++j) ra[h + 2 * j] = sload_a(d, h + 2 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rb[h + 2 * j] = sload_b(d, h + 2 * j);
     }
     // fragments of half h: NP planes of two 32-row blocks per operand (4 NP x ds_read_b128)
     struct Frags { bf16x8 a[2][NP], b[2][NP]; };
@@ -175,12 +188,13 @@ struct SplitCore : FastCore<true, REGION> {
     // bf16 32x32x16 MFMA occupies the pipe for 32 cycles = 8 issue slots).  The registers just stored are refilled
     // with the same half of the slab after next.
     template <bool RELU>
-    __device__ __forceinline__ void fused(int hs, int hc, const Srds& next, float4 (&ra)[4], float4 (&rb)[4], f32x16 (&acc)[2][2]) const {
+    __device__ __forceinline__ void fused(int hs, int hc, const Srds& next, float4 (&ra)[4], float4 (&rb)[4], f32x16 (&acc)[2][2],
+                                          int held_abf) const {
         __builtin_amdgcn_sched_barrier(0);       // the interleaving pattern below applies to this block only
         // fragment reads first in program order: the LDS writes below cannot be proven disjoint from them and would
         // otherwise pin the reads (and with them every MFMA) behind the whole conversion
         const Frags f = read_frags(hc);
-        store_half<RELU>(hs, ra, rb);
+        store_half<RELU>(hs, ra, rb, held_abf);
         mfmas(f, acc);
         load_half(hs, next, ra, rb);
         if (NP == 3) {
@@ -211,18 +225,21 @@ struct SplitCore : FastCore<true, REGION> {
     template <bool RELU>
     __device__ __forceinline__ void run_t(f32x16 (&acc)[2][2]) const {
         float4 ra[4], rb[4];
+        int held;                  // format of the A rows currently in the registers (bf16-stored segment or fp32)
         {
             const Srds d = slab_srds(table[0], true);
             load_half(0, d, ra, rb);
             load_half(1, d, ra, rb);
+            held = d.abf;
         }
-        store_half<RELU>(0, ra, rb);
-        store_half<RELU>(1, ra, rb);
+        store_half<RELU>(0, ra, rb, held);
+        store_half<RELU>(1, ra, rb, held);
         {
             const bool two = nit > 1;
             const Srds d = slab_srds(table[two ? 1 : 0], two);
             load_half(0, d, ra, rb);
             load_half(1, d, ra, rb);
+            held = d.abf;
         }
         __syncthreads();
         compute(0, acc);
@@ -230,9 +247,10 @@ struct SplitCore : FastCore<true, REGION> {
             const bool live = it + 2 < nit;
             const Srds nx = slab_srds(table[live ? it + 2 : it + 1], live);      // once per slab, shared by both halves
             __syncthreads();
-            fused<RELU>(0, 1, nx, ra, rb, acc);
+            fused<RELU>(0, 1, nx, ra, rb, acc, held);
             __syncthreads();
-            fused<RELU>(1, 0, nx, ra, rb, acc);
+            fused<RELU>(1, 0, nx, ra, rb, acc, held);
+            held = nx.abf;
         }
         __syncthreads();
         compute(1, acc);
@@ -242,10 +260,21 @@ struct SplitCore : FastCore<true, REGION> {
     // FastCore::for_each_vec, which is what lets a third workgroup onto the CU.
     template <class F>
     __device__ __forceinline__ void for_each_vec_halves(f32x16 (&acc)[2][2], const F& f) const {
+        constexpr int RR = F::ROUND_ROWS / 2;      // a thread owns 8 rows of each half; half the round of the 256-VGPR cores
+        static_assert(RR == 4 || RR == 8, "rows per epilogue round");   // (these kernels are capped at 168 VGPRs: three workgroups per CU)
         const int lr = lane & 31, lh = lane >> 5;
         const int c = Base::ecol();
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            // first round of auxiliary loads before the half is staged (see FastCore::for_each_vec)
+            typename F::Aux aux[RR];
+            if (c < N) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const int r = half * 64 + (tid >> 5) + 8 * j;
+                    if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                }
+            }
             __syncthreads();
             if (wr == half) {
 #pragma unroll
@@ -259,16 +288,17 @@ struct SplitCore : FastCore<true, REGION> {
             __syncthreads();
             if (c < N) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    typename F::Aux aux[4];
+                for (int g = 0; g < 8 / RR; ++g) {
+                    if (g > 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = half * 64 + (tid >> 5) + 8 * (4 * g + j);
-                        if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                        for (int j = 0; j < RR; ++j) {
+                            const int r = half * 64 + (tid >> 5) + 8 * (RR * g + j);
+                            if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                        }
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int rl = (tid >> 5) + 8 * (4 * g + j), r = half * 64 + rl;
+                    for (int j = 0; j < RR; ++j) {
+                        const int rl = (tid >> 5) + 8 * (RR * g + j), r = half * 64 + rl;
                         if (r < rm.nvalid)
                             f.apply(rm.grow(r), c, *reinterpret_cast<const float4*>(lds + rl * G_LDS_KROW + 4 * (tid & 31)), aux[j]);
                     }

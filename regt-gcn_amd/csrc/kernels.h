@@ -14,10 +14,12 @@ struct EpiBiasAct {     // out[m, c] = act(v + bias[c])
 struct EpiGates {       // N = 2C: c <  C: Z = sigmoid(v + b) -> ZR[m, c]
     float* ZR;          //         c >= C: R = sigmoid(v + b) -> ZR[m, c], q[m, c-C] = h[m, c-C] * R
     const float* h; float* q; const float* bias; int C;
+    int q_bf16 = 0;     // q is stored as bf16 (row stride C elements): it only ever feeds matrix-core operands
 };
 struct EpiDgrad1 {      // v = dq[m, c]:  dzr[m, C+c] = v*h*R*(1-R);  dh[m, c] = v*R + p[t]*dOH[node, c]*Z
     const float* h; const float* ZR; const float* dOH; const float* probs;
     float* dzr; float* dh; int C; int T;
+    int dzr_bf16 = 0;   // dzr is stored as bf16 (row stride 2C elements)
 };
 struct EpiDgrad2 {      // ds[m, c] = (dh[m, c] + v) * act'(h[m, c])   (in place on dh)
     float* dh; const float* h; int C; int act; float slope;
@@ -60,6 +62,7 @@ struct WgradArgs {
     // optional second right-hand operand (skinny kernel only): output columns >= nin_split come from Q2 (column j -
     // nin_split).  Two gradients that share P -- dA0 = ds^T x and dA_r = ds^T (L~ x) -- then read P from HBM once.
     const float* Q2 = nullptr; long ldq2 = 0; int nin_split = 0;
+    int p_bf16 = 0, q_bf16 = 0;   // P / Q hold bf16 elements (ldp / ldq in elements); vector kernels only
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t st);
 long wgrad_slab_stride(const WgradArgs& a);
@@ -166,6 +169,7 @@ struct CellBwdArgs {
     float* dhp; float* dzr; float* dp_partial; int num_nodes, T, C; int nodes_per_block;
     // zero-hidden cell (GraphSAGE / GAT models): h == nullptr means H = 0; Z and dzp then are plain (M, C) arrays
     int ldz = 0, lddz = 0;     // row strides of ZR and dzr in floats; 0 = 2C ([Z|R] and [dzp|drp] layouts of the GRU cell)
+    int out_bf16 = 0;   // dhp / dzr are stored as bf16 (same element strides)
 };
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st);
 int cell_bwd_blocks(int num_nodes, int nodes_per_block);
