@@ -204,13 +204,24 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     ``region_owner[r]`` is the rank that owns region r (its nodes lie inside that rank's range)."""
     topo = shard_topology(edge_index.cpu().numpy(), owner_bounds, rank, world)
     lo, hi = topo.node_lo, topo.node_hi
-    # global A_hat (global degrees), then keep the rows of the owned nodes
+    # A_hat needs GLOBAL degrees (the deterministic, edge-ordered sums of graph.hip): normalise the global edge list on this
+    # rank's GPU, then keep the rows of the owned nodes and remap their columns to the extended input -- all on the device
+    # (the slice bounds are the only values read back).  One-time work per static graph; the replacement that avoids
+    # touching foreign rows at all is own rows + an all-gather of the degree vector (DESIGN.md section 7).
     rp, col, val = gcn_csr(edge_index.to(device), None if gcn_weight is None else gcn_weight.to(device), num_nodes)
-    rp_h = rp.cpu().numpy().astype(np.int64)
-    b, e = rp_h[lo], rp_h[hi]
-    col_loc = topo.remap_columns(col[b:e].cpu().numpy(), owner_bounds)
-    rp_a = torch.from_numpy((rp_h[lo:hi + 1] - b).astype(np.int32)).to(device)
-    col_a = torch.from_numpy(col_loc.astype(np.int32)).to(device)
+    b, e = (int(v) for v in rp[[lo, hi]].tolist())
+    rp_a = (rp[lo:hi + 1] - b).to(torch.int32).contiguous()
+    cols = col[b:e].long()
+    local = (cols >= lo) & (cols < hi)
+    halo = torch.from_numpy(topo.halo_ids()).to(device)               # ascending global ids of the halo rows
+    pos = torch.searchsorted(halo, cols.clamp(min=0)) if halo.numel() else torch.zeros_like(cols)
+    if halo.numel():
+        hit = halo[pos.clamp(max=halo.numel() - 1)] == cols
+    else:
+        hit = torch.zeros_like(local)
+    if not bool((local | hit).all()):
+        raise RuntimeError("halo source is not in this rank's need list")
+    col_a = torch.where(local, cols - lo, topo.n_local + pos).to(torch.int32).contiguous()
     val_a = val[b:e].contiguous()
     # regional Laplacians of the owned regions, in local ids
     mine = [r for r in range(len(region_index)) if region_owner[r] == rank]
