@@ -49,7 +49,8 @@ int main(int argc, char** argv) {
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2 - 1;
     hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const size_t ldsb = 64 * 1024;     // two workgroups per CU by LDS
+    const size_t ldsb = (size_t)(128 / per_cu) * 1024;     // exactly per_cu workgroups per CU by LDS
+    for (int round = 0; round < 3; ++round)                  // three rounds: the first launches run on a cold (low) clock
     for (int var = 0; var < 4; ++var) {
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
@@ -62,7 +63,7 @@ int main(int argc, char** argv) {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             double fl = (double)blocks * 4 * iters * 32.0 * 4096;
-            if (rep) printf("blocks/CU %d variant %d: %.3f ms  %.1f TFLOP/s\n", per_cu, var, ms, fl / ms / 1e9);
+            if (rep) printf("round %d blocks/CU %d variant %d: %.3f ms  %.1f TFLOP/s\n", round, per_cu, var, ms, fl / ms / 1e9);
         }
     }
     std::vector<int> hb(blocks);
