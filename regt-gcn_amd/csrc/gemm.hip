@@ -327,7 +327,9 @@ constexpr long SMALL_TILE_LIMIT = 128;
 
 template <class EpiF, bool BT, bool REGION>
 static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
-    if (gemm_mode() == 0 && (long)cdiv(M, GBM) * cdiv(N, GBN) < SMALL_TILE_LIMIT) {
+    static int force_small = -1;
+    if (force_small < 0) { const char* e = getenv("REGT_SMALL_TILES"); force_small = e ? atoi(e) : 0; }
+    if (gemm_mode() == 0 && (force_small || (long)cdiv(M, GBM) * cdiv(N, GBN) < SMALL_TILE_LIMIT)) {
         const long tiles = (long)cdiv(M, SM_B) * cdiv(N, SM_B);
         hipLaunchKernelGGL((gemm_flat_small_kernel<EpiF, BT, REGION>), dim3((unsigned)tiles), dim3(256), SM_LDS_BYTES, st, S, M, N, f,
                            relu);

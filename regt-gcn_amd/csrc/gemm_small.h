@@ -4,8 +4,8 @@
 // 4x the workgroups and a quarter of the MFMA chain per wave; nothing else changes: same segments, region masking,
 // iteration table, buffer-descriptor loads (FastCore's statics), LDS row padding and epilogue functors.
 //
-// 256 threads = 4 waves 2 x 2, each wave ONE v_mfma_f32_32x32x2_f32 tile.  No scheduling tricks: operands of problems
-// this small come from L2 and there are four co-resident workgroups per CU to cover each other.
+// 256 threads = 4 waves 2 x 2, each wave one 32 x 32 tile as 2 x 2 fragments of v_mfma_f32_16x16x4_f32.  No scheduling
+// tricks: operands of problems this small come from L2 and there are four co-resident workgroups per CU to cover each other.
 #pragma once
 #include "gemm_fast.h"
 
@@ -124,24 +124,52 @@ struct SmallCore {
         if (BT) *reinterpret_cast<float4*>(lb + (slot >> 3) * G_LDS_ROW + 4 * (slot & 7)) = b;
         else *reinterpret_cast<float4*>(lb + (slot >> 4) * SM_KROW + 4 * (slot & 15)) = b;
     }
+    // The wave's 32 x 32 tile as 2 x 2 fragments of v_mfma_f32_16x16x4_f32: acc[(mi * 2 + ni) * 4 + r] = C[16 mi + 4 (lane / 16) + r]
+    // [16 ni + lane % 16].  This shape keeps the full fp32 matrix rate at four waves per SIMD (the occupancy of this kernel:
+    // four workgroups per CU), where 32x32x2 drops to 0.64 of it (tools/micro/mfma_prio.hip).
     __device__ __forceinline__ void mfma_slab(const float* st, f32x16& acc) const {
-        const int lr = lane & 31, lh = lane >> 5;
+        const int lr = lane & 15, lq = lane >> 4;
         const float* lb = st + SM_TILE;
+        f32x4 c[2][2];
 #pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const float4 a = *reinterpret_cast<const float4*>(st + (wr * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
-            float4 b;
-            if (BT) {
-                b = *reinterpret_cast<const float4*>(lb + (wc * 32 + lr) * G_LDS_ROW + kg * 8 + lh * 4);
-            } else {
-                const float* q = lb + (kg * 8 + lh * 4) * SM_KROW + wc * 32 + lr;
-                b = make_float4(q[0], q[SM_KROW], q[2 * SM_KROW], q[3 * SM_KROW]);
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c[mi][ni][r] = acc[(mi * 2 + ni) * 4 + r];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {          // 16 k per group: lane quarter lq supplies k = 16 kg + 4 lq + j to MFMA j
+            float4 a[2], b[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                a[mi] = *reinterpret_cast<const float4*>(st + (wr * 32 + mi * 16 + lr) * G_LDS_ROW + kg * 16 + lq * 4);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                if (BT) {
+                    b[ni] = *reinterpret_cast<const float4*>(lb + (wc * 32 + ni * 16 + lr) * G_LDS_ROW + kg * 16 + lq * 4);
+                } else {
+                    const float* q = lb + (kg * 16 + lq * 4) * SM_KROW + wc * 32 + ni * 16 + lr;
+                    b[ni] = make_float4(q[0], q[SM_KROW], q[2 * SM_KROW], q[3 * SM_KROW]);
+                }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+            const float* af0 = reinterpret_cast<const float*>(&a[0]);
+            const float* af1 = reinterpret_cast<const float*>(&a[1]);
+            const float* bf0 = reinterpret_cast<const float*>(&b[0]);
+            const float* bf1 = reinterpret_cast<const float*>(&b[1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                c[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf0[j], c[0][0], 0, 0, 0);
+                c[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[j], bf1[j], c[0][1], 0, 0, 0);
+                c[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf0[j], c[1][0], 0, 0, 0);
+                c[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af1[j], bf1[j], c[1][1], 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[(mi * 2 + ni) * 4 + r] = c[mi][ni][r];
     }
 
     __device__ __forceinline__ void run(f32x16& acc, bool relu_a) const {
@@ -172,10 +200,14 @@ struct SmallCore {
 
     // LDS-staged vector epilogue: 16 threads per 64-column row, 16 rows per pass, 4 passes
     __device__ __forceinline__ void stage(const f32x16& acc) const {
-        const int lr = lane & 31, lh = lane >> 5;
+        const int lr = lane & 15, lq = lane >> 4;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg)
-            lds[(wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * SM_KROW + wc * 32 + lr] = acc[reg];
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    lds[(wr * 32 + mi * 16 + 4 * lq + r) * SM_KROW + wc * 32 + ni * 16 + lr] = acc[(mi * 2 + ni) * 4 + r];
         __syncthreads();
     }
     __device__ __forceinline__ int erow(int i) const { return (tid >> 4) + 16 * i; }
