@@ -358,7 +358,8 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* H = h_ext ? h_ext : L.h;
-    const int qbf = bf16_intermediates(d) ? 1 : 0;
+    const int qbf = bf16_intermediates(d) ? 1 : 0;      // q (and dhp, dzp|drp in the backward) stored as bf16
+    const int abf = qbf && !h_ext ? 1 : 0;              // ... and h, [Z|R], H~ (dh in the backward) too: everything M x C
     {
         PROF("compose_fwd", st);
         TRY(launch_softmax_small(p.attention, L.probs, T, st));
@@ -399,6 +400,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         region_range(d, g, &lo, &hi);
         S.num_regions = hi - lo;                 // a row tile can only meet the regions that own rows here
         EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        e.out_bf16 = abf;
         PROF("gemm_regional", st);
         TRY(launch_gemm_bias_act(S, M, C, e, st));
     }
@@ -406,11 +408,11 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true);
+        S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true, abf ? SEG_A_BF16 : 0);
         S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         S.row_div = T;
         EpiGates e{L.ZR, H, L.q, L.czr, C};
-        e.q_bf16 = qbf;
+        e.q_bf16 = qbf; e.h_bf16 = abf; e.zr_bf16 = abf;
         PROF("gemm_gates", st);
         TRY(launch_gemm_gates(S, M, 2 * C, e, st));
     }
@@ -423,6 +425,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         a.S.row_div = T;
         a.num_nodes = N; a.T = T; a.C = C;
         a.bias = L.ch; a.ZR = L.ZR; a.h = H; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
+        a.act_bf16 = abf;
         PROF("gemm_candidate", st);
         TRY(launch_gemm_candidate(a, st));
     }
@@ -540,13 +543,14 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
     const int ibf = bf16_intermediates(d) ? 1 : 0;      // dhp, dzp|drp stored as bf16 (and q, by the forward: checked by the caller)
+    const int abf = ibf && !h_ext ? 1 : 0;              // h, [Z|R], H~ were stored as bf16 by the forward; dh / ds follow
     // ---- head ----------------------------------------------------------------------------------
     ReduceQueue rq(L.slab, L.slab_floats, st);
     TRY(head_backward(d, p, gr, dpred, dhidden, hidden, L.y1, L.d1, L.dOH, L.kchunk_head, L.nchunks_head, rq, st));
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
-        a.out_bf16 = ibf;
+        a.out_bf16 = ibf; a.in_bf16 = abf;
         PROF("cell_bwd", st);
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
@@ -564,7 +568,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         else S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad1 e{H, L.ZR, L.dOH, L.probs, L.dzr, DH, C, T};
-        e.dzr_bf16 = ibf;
+        e.dzr_bf16 = ibf; e.h_bf16 = abf; e.zr_bf16 = abf; e.dh_bf16 = abf;
         PROF("dgrad_candidate", st);
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
     }
@@ -581,6 +585,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         }
         S.row_div = T;
         EpiDgrad2 e{DH, H, C, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
+        e.h_bf16 = abf; e.dh_bf16 = abf;
         PROF("dgrad_gates", st);
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
@@ -589,7 +594,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st, ibf, 0));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
-        a.p_bf16 = ibf;
+        a.p_bf16 = ibf; a.q_bf16 = abf;
         TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Uzr", st);
@@ -615,6 +620,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, Xp, F, 2 * F, 0, M, 0, g.chunk_tab, g.n_chunks, nullptr, 1};
         a.Q2 = L.LX; a.ldq2 = F; a.nin_split = F;
+        a.p_bf16 = abf;
         TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_A0_Ar", st);
@@ -634,16 +640,17 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         r1.group_stride = (long)C * F;
         TRY(rq.push(r1));
     }
-    if (!h_ext && !fuse_a) TRY(wgrad_full(rq, "wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, dA0, F, dbpr, st));
+    if (!h_ext && !fuse_a) TRY(wgrad_full(rq, "wgrad_A0", L.dh, C, C, Xp, F, F, 0, M, L.kchunk_s, L.nchunks_s, dA0, F, dbpr, st, abf, 0));
     if (h_ext || fuse_a) {
         // no embedding stage behind a caller-supplied hidden input / already done above
     } else if (g.overlap) {   // one unmasked (C x F) gradient per region: dA_r = ds^T (L~_r x)
         for (int r = 0; r < R; ++r)
             TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX + (long)r * M * F, F, F, 0, M, L.kchunk_s, L.nchunks_s,
-                           dAall + (long)r * C * F, F, nullptr, st));
+                           dAall + (long)r * C * F, F, nullptr, st, abf, 0));
     } else if (R > 1) {   // per-region dA_r = sum over the region's rows of ds^T (L~ x)
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, L.LX, F, F, 0, M, 0, g.chunk_tab, g.n_chunks, nullptr, 0};
+        a.p_bf16 = abf;
         TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Ar", st);
@@ -655,7 +662,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         r.group_stride = (long)C * F;
         TRY(rq.push(r));
     } else {
-        TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, dAall, F, nullptr, st));
+        TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, dAall, F, nullptr, st, abf, 0));
     }
     TRY(rq.flush());      // every slab reduction of this backward pass, one launch
     // ---- back through the weight compositions (tiny; two launches) ---------------------------------------

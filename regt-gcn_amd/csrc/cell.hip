@@ -84,6 +84,81 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(CellBwdArgs a) {
         a.dp_partial[(long)blockIdx.x * a.T + t] = (dp[0][t] + dp[1][t]) + (dp[2][t] + dp[3][t]);
 }
 
+// The same with Z, h, H~ stored as bf16 and dhp / dzp written as bf16 (REGT_GEMM_MODE=bf16): a lane owns 8 columns (16 bytes
+// of every array), a half wave one (node, t) row, so a wave handles two periods per pass.
+__device__ __forceinline__ void widen8(const uint4 raw, float (&v)[8]) {
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+    v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 narrow8(const float (&v)[8]) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    uint4 raw;
+    const f32x2_t a = {v[0], v[1]}, b = {v[2], v[3]}, c = {v[4], v[5]}, d = {v[6], v[7]};
+    raw.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t));
+    raw.y = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t));
+    raw.z = __builtin_bit_cast(unsigned, __builtin_convertvector(c, bf16x2_t));
+    raw.w = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_t));
+    return raw;
+}
+__global__ __launch_bounds__(256) void cell_bwd8_kernel(CellBwdArgs a) {
+    __shared__ float dp[4][CB_MAXT];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int hl = lane & 31, half = lane >> 5;
+    for (int t = lane; t < a.T; t += 64) dp[wid][t] = 0.f;
+    const long C = a.C;
+    const int C8 = a.C / 8;
+    const long ldz = a.ldz ? a.ldz : 2 * C, lddz = a.lddz ? a.lddz : 2 * C;
+    const char* Zb = reinterpret_cast<const char*>(a.ZR);
+    const char* Hb = reinterpret_cast<const char*>(a.h);
+    const char* Tb = reinterpret_cast<const char*>(a.Ht);
+    char* Pb = reinterpret_cast<char*>(a.dhp);
+    char* Db = reinterpret_cast<char*>(a.dzr);
+    const int n0 = blockIdx.x * a.nodes_per_block;
+    const int n1 = n0 + a.nodes_per_block < a.num_nodes ? n0 + a.nodes_per_block : a.num_nodes;
+    for (int node = n0 + wid; node < n1; node += 4) {
+        for (int t0 = 0; t0 < a.T; t0 += 2) {
+            const int t = t0 + half;
+            const bool live = t < a.T;
+            const long m = (long)node * a.T + (live ? t : 0);
+            const float pt = live ? a.probs[t] : 0.f;
+            float dot = 0.f;
+            if (live) {
+                for (int c8 = hl; c8 < C8; c8 += 32) {
+                    const float4 d0 = reinterpret_cast<const float4*>(a.dOH + node * C)[2 * c8];
+                    const float4 d1 = reinterpret_cast<const float4*>(a.dOH + node * C)[2 * c8 + 1];
+                    const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+                    float z[8], h[8], ht[8], dhp[8], dzp[8];
+                    widen8(*reinterpret_cast<const uint4*>(Zb + 2 * (m * ldz + 8 * c8)), z);
+                    widen8(*reinterpret_cast<const uint4*>(Tb + 2 * (m * C + 8 * c8)), ht);
+                    if (a.h) widen8(*reinterpret_cast<const uint4*>(Hb + 2 * (m * C + 8 * c8)), h);
+                    else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) h[k] = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float g = pt * dd[k];
+                        dhp[k] = g * (1.0f - z[k]) * (1.0f - ht[k] * ht[k]);
+                        dzp[k] = g * (h[k] - ht[k]) * (z[k] * (1.0f - z[k]));
+                        dot += dd[k] * (z[k] * h[k] + (1.0f - z[k]) * ht[k]);
+                    }
+                    *reinterpret_cast<uint4*>(Pb + 2 * (m * C + 8 * c8)) = narrow8(dhp);
+                    *reinterpret_cast<uint4*>(Db + 2 * (m * lddz + 8 * c8)) = narrow8(dzp);
+                }
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);      // inside each half wave
+            if (hl == 0 && live) dp[wid][t] += dot;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < a.T; t += 256)
+        a.dp_partial[(long)blockIdx.x * a.T + t] = (dp[0][t] + dp[1][t]) + (dp[2][t] + dp[3][t]);
+}
+
 int cell_bwd_blocks(int num_nodes, int nodes_per_block) { return cdiv(num_nodes, nodes_per_block); }
 
 // Zero-hidden cell (the reference's GraphSAGE / GAT models call the cell with H = None -> zeros, models/utils.py:163-166):
@@ -121,7 +196,12 @@ int launch_blend0_fwd(const float* Z, const float* Ht, const float* probs, float
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.T <= CB_MAXT, "cell_bwd: T=%d exceeds %d", a.T, CB_MAXT);
     REGT_CHECK_ARG(a.C % 4 == 0, "cell_bwd: C must be a multiple of 4");
-    hipLaunchKernelGGL(cell_bwd_kernel, dim3(cell_bwd_blocks(a.num_nodes, a.nodes_per_block)), dim3(256), 0, st, a);
+    if (a.in_bf16) {
+        REGT_CHECK_ARG(a.out_bf16 && a.C % 8 == 0, "cell_bwd: bf16-stored activations need bf16 outputs and C %% 8 == 0");
+        hipLaunchKernelGGL(cell_bwd8_kernel, dim3(cell_bwd_blocks(a.num_nodes, a.nodes_per_block)), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(cell_bwd_kernel, dim3(cell_bwd_blocks(a.num_nodes, a.nodes_per_block)), dim3(256), 0, st, a);
+    }
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

@@ -175,6 +175,137 @@ struct EpiMaskAddF {
     }
 };
 
+// ---- 8-column-per-thread epilogues (bf16-operand core with bf16 STORAGE of the M x C activations) ------------------------
+// A thread owns 8 consecutive columns of a row: 16 bytes of a bf16 array, two float4 of an fp32 one -- every access of the
+// epilogue stays 16 bytes wide whichever format an array has (8-byte accesses run at about half the rate).
+// Functor interface: ColAux col(c) once per thread (bias), Aux load(m, c) per row (the first round is requested before the
+// accumulators are staged), apply(m, c, v, col, aux).  `bf` flags are wave-uniform.
+struct F8 { float4 lo, hi; };
+__device__ __forceinline__ F8 ld8(const void* base, long elem, int bf) {
+    F8 r;
+    if (bf) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base) + 2 * elem);
+        r.lo = widen_bf16x4(raw.x, raw.y);
+        r.hi = widen_bf16x4(raw.z, raw.w);
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + 4 * elem);
+        r.lo = p[0];
+        r.hi = p[1];
+    }
+    return r;
+}
+__device__ __forceinline__ void st8(void* base, long elem, const F8& v, int bf) {
+    if (bf) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t a = {v.lo.x, v.lo.y}, b = {v.lo.z, v.lo.w}, c = {v.hi.x, v.hi.y}, d = {v.hi.z, v.hi.w};
+        uint4 raw;
+        raw.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t));
+        raw.y = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t));
+        raw.z = __builtin_bit_cast(unsigned, __builtin_convertvector(c, bf16x2_t));
+        raw.w = __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_t));
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + 2 * elem) = raw;
+    } else {
+        float4* p = reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + 4 * elem);
+        p[0] = v.lo;
+        p[1] = v.hi;
+    }
+}
+#define REGT_F8(expr) F8{make_float4(expr(lo.x), expr(lo.y), expr(lo.z), expr(lo.w)), make_float4(expr(hi.x), expr(hi.y), expr(hi.z), expr(hi.w))}
+
+struct EpiBiasAct8F {
+    typedef F8 Vec;
+    EpiBiasAct e;
+    static constexpr int ROUND_ROWS = 4;
+    struct ColAux { F8 b; };
+    struct Aux {};
+    __device__ __forceinline__ float act(float v) const {
+        if (e.act == ACT_SIGMOID) return fast_sigmoid(v);
+        if (e.act == ACT_TANH) return fast_tanh(v);
+        const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
+        return v > 0.f ? v : v * ns;
+    }
+    __device__ __forceinline__ ColAux col(int c) const {
+        return ColAux{e.bias ? ld8(e.bias, c, 0) : F8{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}};
+    }
+    __device__ __forceinline__ Aux load(long, int) const { return Aux{}; }
+    __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux& ca, const Aux&) const {
+#define F_(k) act(v.k + ca.b.k)
+        st8(e.out, m * e.ldo + c, REGT_F8(F_), e.out_bf16);
+#undef F_
+    }
+};
+struct EpiGates8F {
+    typedef F8 Vec;
+    EpiGates e;
+    static constexpr int ROUND_ROWS = 4;
+    struct ColAux { F8 b; };
+    struct Aux { F8 h; };
+    __device__ __forceinline__ ColAux col(int c) const { return ColAux{ld8(e.bias, c, 0)}; }
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        Aux a;
+        if (c >= e.C) a.h = ld8(e.h, m * e.C + c - e.C, e.h_bf16);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux& ca, const Aux& a) const {
+#define F_(k) fast_sigmoid(v.k + ca.b.k)
+        const F8 g = REGT_F8(F_);
+#undef F_
+        st8(e.ZR, m * (2L * e.C) + c, g, e.zr_bf16);
+        if (c >= e.C) {
+#define F_(k) (a.h.k * g.k)
+            st8(e.q, m * e.C + c - e.C, REGT_F8(F_), e.q_bf16);
+#undef F_
+        }
+    }
+};
+struct EpiDgrad18F {
+    typedef F8 Vec;
+    EpiDgrad1 e;
+    static constexpr int ROUND_ROWS = 1;      // 33 registers of auxiliary operands per row under the 168-VGPR cap
+    struct ColAux {};
+    struct Aux { F8 h, Z, R, d; float p; };
+    __device__ __forceinline__ ColAux col(int) const { return ColAux{}; }
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        const long node = m / e.T;
+        Aux a;
+        a.p = e.probs[(int)(m - node * e.T)];
+        a.h = ld8(e.h, m * e.C + c, e.h_bf16);
+        a.Z = ld8(e.ZR, m * (2L * e.C) + c, e.zr_bf16);
+        a.R = ld8(e.ZR, m * (2L * e.C) + e.C + c, e.zr_bf16);
+        a.d = ld8(e.dOH, node * e.C + c, 0);
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux&, const Aux& a) const {
+#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+        st8(e.dzr, m * (2L * e.C) + e.C + c, REGT_F8(F_), e.dzr_bf16);
+#undef F_
+#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+        st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
+#undef F_
+    }
+};
+struct EpiDgrad28F {
+    typedef F8 Vec;
+    EpiDgrad2 e;
+    static constexpr int ROUND_ROWS = 4;
+    struct ColAux {};
+    struct Aux { F8 d, h; };
+    __device__ __forceinline__ ColAux col(int) const { return ColAux{}; }
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        Aux a;
+        a.d = ld8(e.dh, m * e.C + c, e.dh_bf16);
+        if (e.act == ACT_LRELU) a.h = ld8(e.h, m * e.C + c, e.h_bf16);
+        else a.h = F8{make_float4(1, 1, 1, 1), make_float4(1, 1, 1, 1)};
+        return a;
+    }
+    __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux&, const Aux& a) const {
+#define F_(k) ((a.d.k + v.k) * (a.h.k > 0.f ? 1.0f : e.slope))
+        st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
+#undef F_
+    }
+};
+
 template <class EpiF>
 __global__ __launch_bounds__(256, 2) void gemm_flat_kernel(GemmSegs S, long M, int N, EpiF epi, int vec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -241,6 +372,28 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     core.run(acc, relu_a != 0);
     core.for_each_vec_halves(acc, epi);
+}
+
+// bf16-operand core + 8-column epilogue (bf16 storage of the activations): same K loop as gemm_flat_split_kernel<.., 1>
+template <class EpiF8, bool REGION>
+__global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, long M, int N, EpiF8 epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    SplitCore<REGION, 1> core(S, rm, n0, N, lds, true);
+    core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    core.run(acc, false);
+    core.for_each_vec8_halves(acc, epi);
 }
 
 // Small problems: 64 x 64 tiles (gemm_small.h) -- same operands, segments and epilogues, a quarter of the work per tile.
@@ -351,6 +504,17 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
     return launch_fast_core<EpiF, FastCore<BT, REGION>>(S, M, N, f, relu, st);
 }
 
+// bf16-operand core with the 8-column epilogue: arrays of the epilogue may be stored as bf16
+template <class EpiF8, bool REGION>
+static int launch_split8(const GemmSegs& S, long M, int N, EpiF8 f, hipStream_t st) {
+    REGT_CHECK_ARG(gemm_mode() == 2 && N % 8 == 0, "gemm: bf16-stored activations need REGT_GEMM_MODE=bf16 and N %% 8 == 0");
+    const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
+    REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
+    hipLaunchKernelGGL((gemm_flat_split8_kernel<EpiF8, REGION>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 template <class EpiF>
 static int launch_flat(const GemmSegs& S, long M, int N, EpiF f, bool vec, hipStream_t st) {
     REGT_CHECK_ARG(M > 0 && N > 0, "gemm: empty problem M=%ld N=%d", M, N);
@@ -370,6 +534,11 @@ static inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) &
 int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st) {
     const bool vec = N % 4 == 0 && e.ldo % 4 == 0 && a16(e.out) && a16(e.bias);
     const int fc = fast_class(S, N, vec);
+    if (e.out_bf16) {
+        REGT_CHECK_ARG(fc >= 0 && (fc & 1) && !(fc & 4) && e.ldo % 8 == 0, "bias/act gemm: bf16 output needs the bf16-operand vector path");
+        if (fc & 2) return launch_split8<EpiBiasAct8F, true>(S, M, N, EpiBiasAct8F{e}, st);
+        return launch_split8<EpiBiasAct8F, false>(S, M, N, EpiBiasAct8F{e}, st);
+    }
     if (fc >= 0 && (fc & 1)) {
         if (fc & 2) return launch_fast<EpiBiasActF, true, true>(S, M, N, EpiBiasActF{e}, (fc >> 2) & 1, st);
         return launch_fast<EpiBiasActF, true, false>(S, M, N, EpiBiasActF{e}, (fc >> 2) & 1, st);
@@ -379,6 +548,10 @@ int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, 
 int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st) {
     REGT_CHECK_ARG(N == 2 * e.C, "gates gemm expects N == 2C");
     const bool vec = e.C % 4 == 0 && a16(e.ZR) && a16(e.h) && a16(e.q) && a16(e.bias);
+    if (e.h_bf16 || e.zr_bf16) {
+        REGT_CHECK_ARG(fast_class(S, N, vec) == 1 && e.C % 8 == 0, "gates gemm: bf16-stored activations need the bf16-operand vector path");
+        return launch_split8<EpiGates8F, false>(S, M, N, EpiGates8F{e}, st);
+    }
     if (fast_class(S, N, vec) == 1) return launch_fast<EpiGatesF, true, false>(S, M, N, EpiGatesF{e}, 0, st);
     REGT_CHECK_ARG(!e.q_bf16, "gates gemm: bf16 storage of q needs the vector path");
     return launch_flat(S, M, N, EpiGatesF{e}, vec, st);
@@ -386,6 +559,10 @@ int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipSt
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad1 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh);
+    if (e.h_bf16 || e.zr_bf16 || e.dh_bf16) {
+        REGT_CHECK_ARG(fast_class(S, N, vec) == 1 && e.C % 8 == 0, "dgrad1 gemm: bf16-stored activations need the bf16-operand vector path");
+        return launch_split8<EpiDgrad18F, false>(S, M, N, EpiDgrad18F{e}, st);
+    }
     if (fast_class(S, N, vec) == 1) return launch_fast<EpiDgrad1F, true, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     REGT_CHECK_ARG(!e.dzr_bf16, "dgrad1 gemm: bf16 storage of dzr needs the bf16-operand vector path");
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad1F, false, false>(S, M, N, EpiDgrad1F{e}, 0, st);
@@ -394,6 +571,10 @@ int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hip
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");
     const bool vec = e.C % 4 == 0 && a16(e.dh) && a16(e.h);
+    if (e.h_bf16 || e.dh_bf16) {
+        REGT_CHECK_ARG(fast_class(S, N, vec) == 1 && e.C % 8 == 0, "dgrad2 gemm: bf16-stored activations need the bf16-operand vector path");
+        return launch_split8<EpiDgrad28F, false>(S, M, N, EpiDgrad28F{e}, st);
+    }
     if (fast_class(S, N, vec) == 1) return launch_fast<EpiDgrad2F, true, false>(S, M, N, EpiDgrad2F{e}, 0, st);
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad2F, false, false>(S, M, N, EpiDgrad2F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad2F{e}, vec, st);
@@ -545,11 +726,101 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
     }
 }
 
+// The same with ZR, h and Ht stored as bf16 (bf16-operand core, REGT_GEMM_MODE=bf16): 8 columns per thread, so that the
+// epilogue's reads of Z and h and its store of H~ are 16-byte accesses.
+__global__ __launch_bounds__(256, 2) void gemm_cand_flat8_kernel(CandArgs a) {
+    using Core = SplitCore<false, 1>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = Core::BM, BN = Core::BN, KROW = Core::EKROW, TPR = Core::ETPR;
+    const long C = a.C, M = (long)a.num_nodes * a.T;
+    const int tiles_n = (a.C + BN - 1) / BN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * BM;
+    const int n0 = (bid % tiles_n) * BN;
+    const RowMap rm{m0, 1, (int)((M - m0) < BM ? (M - m0) : BM)};
+    Core core(a.S, rm, n0, a.C, lds);
+    core.plan();
+    typename Core::Acc acc;
+    Core::zero(acc);
+    core.run(acc, false);
+    const int tid = threadIdx.x;
+    const int c = n0 + 8 * (tid & 15);
+    const int node0 = (int)(m0 / a.T);
+    constexpr int RR = 4;                          // rows per round of the thread's 8 rows (tid >> 4) + 16 i
+    F8 Z[RR], hv[RR];
+    if (c < a.C) {
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int r = (tid >> 4) + 16 * j;
+            if (r < rm.nvalid) {
+                Z[j] = ld8(a.ZR, (m0 + r) * 2 * C + c, 1);
+                hv[j] = ld8(a.h, (m0 + r) * C + c, 1);
+            }
+        }
+    }
+    core.stage(acc);
+    if (c < a.C) {
+        const F8 b = ld8(a.bias, c, 0);
+#pragma unroll
+        for (int g = 0; g < 8 / RR; ++g) {
+            if (g > 0) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const int r = (tid >> 4) + 16 * (RR * g + j);
+                    if (r < rm.nvalid) {
+                        Z[j] = ld8(a.ZR, (m0 + r) * 2 * C + c, 1);
+                        hv[j] = ld8(a.h, (m0 + r) * C + c, 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                const int r = (tid >> 4) + 16 * (RR * g + j);
+                if (r < rm.nvalid) {
+                    const long m = m0 + r;
+                    const float pt = a.probs[(int)(m % a.T)];
+                    float4* img = reinterpret_cast<float4*>(lds + r * KROW + 8 * (tid & 15));
+                    const F8 v{img[0], img[1]};
+#define F_(k) fast_tanh(v.k + b.k)
+                    const F8 ht = REGT_F8(F_);
+#undef F_
+                    st8(a.Ht, m * C + c, ht, 1);
+#define F_(k) (pt * (Z[j].k * hv[j].k + (1.0f - Z[j].k) * ht.k))
+                    const F8 o = REGT_F8(F_);
+#undef F_
+                    img[0] = o.lo;                 // own elements of the staged tile
+                    img[1] = o.hi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // segmented sum over each node's rows inside the tile (as gemm_cand_flat_kernel)
+    const int node1 = (int)((m0 + rm.nvalid - 1) / a.T);
+    const int items = (node1 - node0 + 1) * TPR;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int node = node0 + it / TPR, c4 = it % TPR;
+        const int cc = n0 + 4 * c4;
+        if (cc >= a.C) continue;
+        long lo = (long)node * a.T - m0, hi = lo + a.T - 1;
+        if (lo < 0) lo = 0;
+        if (hi > rm.nvalid - 1) hi = rm.nvalid - 1;
+        float4 s4 = make_float4(0, 0, 0, 0);
+        for (long r = lo; r <= hi; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * KROW + 4 * c4);
+            s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+        }
+        float* o = a.OH + (long)node * C + cc;
+        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+    }
+}
+
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
     const bool vec = a.C % 4 == 0 && a16(a.ZR) && a16(a.h) && a16(a.Ht) && a16(a.OH) && a16(a.bias) &&
                      fast_class(a.S, a.C, true) == 1;
+    REGT_CHECK_ARG(!a.act_bf16 || (vec && gemm_mode() == 2), "candidate gemm: bf16-stored activations need the bf16-operand vector path");
     if (vec) {
         static bool attr_done = false, attr_done_split = false, attr_done_bf16 = false;
         if (int rc = set_lds_once(&gemm_cand_flat_kernel<FastCore<true, false>>, G_FAST_LDS_BYTES, &attr_done)) return rc;
@@ -561,7 +832,12 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
         if (gemm_mode() == 1)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 3>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
-        else if (gemm_mode() == 2)
+        else if (gemm_mode() == 2 && a.act_bf16) {
+            static bool attr_done8 = false;
+            REGT_CHECK_ARG(a.C % 8 == 0, "candidate gemm: bf16 storage needs C %% 8 == 0");
+            if (int rc = set_lds_once(&gemm_cand_flat8_kernel, G_FAST_LDS_BYTES, &attr_done8)) return rc;
+            hipLaunchKernelGGL(gemm_cand_flat8_kernel, dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        } else if (gemm_mode() == 2)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 1>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
         else if (ftiles < SMALL_TILE_LIMIT)      // small graph: 64 x 64 tiles (a node's T <= 64 rows still span at most two)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SmallCore<true, false>>), dim3((unsigned)(cdiv(M, SM_B) * cdiv(a.C, SM_B))),

@@ -308,6 +308,62 @@ struct SplitCore : FastCore<true, REGION> {
         __syncthreads();
     }
 
+    // 8-column-per-thread form of the half-tile epilogue (functors of gemm.hip's "8F" family): thread = (row tid >> 4 (+16 i),
+    // columns 8 (tid & 15) .. +7) -- 16 bytes per access of a bf16 array, two float4 of an fp32 one.
+    template <class F>
+    __device__ __forceinline__ void for_each_vec8_halves(f32x16 (&acc)[2][2], const F& f) const {
+        constexpr int RR = F::ROUND_ROWS;          // of the thread's 4 rows per half
+        static_assert(RR == 1 || RR == 2 || RR == 4, "rows per epilogue round");
+        const int lr = lane & 31, lh = lane >> 5;
+        const int c = n0 + 8 * (tid & 15);
+        const bool live = c < N;
+        typename F::ColAux ca;
+        if (live) ca = f.col(c);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            typename F::Aux aux[RR];
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const int r = half * 64 + (tid >> 4) + 16 * j;
+                    if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                }
+            }
+            __syncthreads();
+            if (wr == half) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg)
+                            lds[(mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * G_LDS_KROW + wc * 64 + ni * 32 + lr] = acc[mi][ni][reg];
+            }
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int g = 0; g < 4 / RR; ++g) {
+                    if (g > 0) {
+#pragma unroll
+                        for (int j = 0; j < RR; ++j) {
+                            const int r = half * 64 + (tid >> 4) + 16 * (RR * g + j);
+                            if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < RR; ++j) {
+                        const int rl = (tid >> 4) + 16 * (RR * g + j), r = half * 64 + rl;
+                        if (r < rm.nvalid) {
+                            const float4* img = reinterpret_cast<const float4*>(lds + rl * G_LDS_KROW + 8 * (tid & 15));
+                            f.apply(rm.grow(r), c, typename F::Vec{img[0], img[1]}, ca, aux[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
     __device__ __forceinline__ void run(f32x16 (&acc)[2][2], bool relu_a) const {
         if (nit == 0) return;
         if (relu_a) run_t<true>(acc);            // head only: relu on A while staging

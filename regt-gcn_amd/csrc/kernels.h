@@ -8,21 +8,27 @@ namespace regt {
 // ---- epilogue descriptors for the flat segmented GEMM ------------------------------------------
 enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
 
+// `*_bf16` flags (REGT_GEMM_MODE=bf16 with bf16 storage of the M x C activations): the array holds bf16 elements (strides
+// in elements); the bf16-operand core then runs its 8-column-per-thread epilogue so that every access stays 16 bytes wide.
 struct EpiBiasAct {     // out[m, c] = act(v + bias[c])
     float* out; long ldo; const float* bias; int act; float slope;
+    int out_bf16 = 0;
 };
 struct EpiGates {       // N = 2C: c <  C: Z = sigmoid(v + b) -> ZR[m, c]
     float* ZR;          //         c >= C: R = sigmoid(v + b) -> ZR[m, c], q[m, c-C] = h[m, c-C] * R
     const float* h; float* q; const float* bias; int C;
     int q_bf16 = 0;     // q is stored as bf16 (row stride C elements): it only ever feeds matrix-core operands
+    int h_bf16 = 0, zr_bf16 = 0;
 };
 struct EpiDgrad1 {      // v = dq[m, c]:  dzr[m, C+c] = v*h*R*(1-R);  dh[m, c] = v*R + p[t]*dOH[node, c]*Z
     const float* h; const float* ZR; const float* dOH; const float* probs;
     float* dzr; float* dh; int C; int T;
     int dzr_bf16 = 0;   // dzr is stored as bf16 (row stride 2C elements)
+    int h_bf16 = 0, zr_bf16 = 0, dh_bf16 = 0;
 };
 struct EpiDgrad2 {      // ds[m, c] = (dh[m, c] + v) * act'(h[m, c])   (in place on dh)
     float* dh; const float* h; int C; int act; float slope;
+    int h_bf16 = 0, dh_bf16 = 0;
 };
 struct EpiMaskAdd {     // out[m, c] = v * (mask[m, c] > 0) + (add ? add[m, c] : 0)
     float* out; long ldo; const float* mask; long ldm; const float* add; long ldadd;
@@ -45,6 +51,7 @@ struct CandArgs {
     const float* probs;     // (T)
     float* Ht;              // (M, C) out
     float* OH;              // (num_nodes, C) out
+    int act_bf16 = 0;       // ZR, h and Ht hold bf16 elements (all three together)
 };
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st);
 
@@ -170,6 +177,7 @@ struct CellBwdArgs {
     // zero-hidden cell (GraphSAGE / GAT models): h == nullptr means H = 0; Z and dzp then are plain (M, C) arrays
     int ldz = 0, lddz = 0;     // row strides of ZR and dzr in floats; 0 = 2C ([Z|R] and [dzp|drp] layouts of the GRU cell)
     int out_bf16 = 0;   // dhp / dzr are stored as bf16 (same element strides)
+    int in_bf16 = 0;    // ZR, h and Ht hold bf16 elements (all three together; needs out_bf16 and C % 8 == 0)
 };
 int launch_cell_bwd(const CellBwdArgs& a, hipStream_t st);
 int cell_bwd_blocks(int num_nodes, int nodes_per_block);

@@ -53,13 +53,16 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None):
+def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None, store=None):
     """x (N,F,T).  Returns (pred, hidden) through the composed-weight formulation using autograd.
 
     ``rnd``: optional rounding applied to both operands of every activation x weight contraction that the HIP path
     runs on the matrix cores (``bf16_round`` emulates REGT_GEMM_MODE=bf16; accumulation, SpMM, compositions, gate
-    math and the skinny last head layer stay fp32, as in the kernels)."""
+    math and the skinny last head layer stay fp32, as in the kernels).  ``store``: rounding applied to the M x C
+    activations the pipeline keeps in HBM between kernels (h, Z; ``bf16_round`` when that mode stores them as bf16):
+    whatever reads them later -- the GRU blend here -- sees the stored value."""
     q = (lambda v: v) if rnd is None else rnd
+    st = (lambda v: v) if store is None else store
     n, f, t = x.shape
     R = len(l_list)
     w = compose(p, R, regional)
@@ -68,11 +71,11 @@ def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None):
     pre = q(xp) @ q(w["A0"]).t() + w["b"]
     for r in range(R):
         pre = pre + q(torch.einsum("ij,jtf->itf", l_list[r], xp)) @ q(w["Ar"][r]).t()
-    h = torch.nn.functional.leaky_relu(pre, LRELU) if regional else pre
+    h = st(torch.nn.functional.leaky_relu(pre, LRELU) if regional else pre)
     z = torch.sigmoid(q(h) @ q(w["Uz"]).t() + q(ax) @ q(w["Gz"]).t() + w["cz"])
     r_ = torch.sigmoid(q(h) @ q(w["Ur"]).t() + q(ax) @ q(w["Gr"]).t() + w["cr"])
     ht = torch.tanh(q(h * r_) @ q(w["Uh"]).t() + q(ax) @ q(w["Gh"]).t() + w["ch"])
-    hn = z * h + (1 - z) * ht
+    hn = st(z) * h + (1 - st(z)) * ht
     probs = torch.softmax(p["tgnn._attention"], dim=0)
     hidden = (hn * probs.view(1, t, 1)).sum(dim=1)
     y = q(torch.relu(hidden)) @ q(p["linear1.weight"]).t() + p["linear1.bias"]

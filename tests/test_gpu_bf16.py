@@ -1,16 +1,17 @@
-"""Reduced-precision GEMM mode of BASELINE configs[4] (REGT_GEMM_MODE=bf16 / regt_set_gemm_mode(2)): activations and
-weights are rounded to bf16 (round-to-nearest-even) while they are staged into LDS, v_mfma_f32_32x32x16_bf16 accumulates in
-fp32; SpMM, weight compositions, gate math, reductions and the skinny (C x F) gradients stay fp32.
+"""Reduced-precision mode of BASELINE configs[4] (REGT_GEMM_MODE=bf16 / regt_set_gemm_mode(2)): activations and weights enter
+the matrix cores as bf16 (round-to-nearest-even), v_mfma_f32_32x32x16_bf16 accumulates in fp32, and the M x C activations the
+pipeline keeps in HBM between kernels (h, [Z|R], H~, q and the backward's dhp, dzp|drp, dh) are stored as bf16; SpMM, weight
+compositions, gate math (in registers), reductions, the per-node hidden state and the head stay fp32.
 
 The reference has no bf16 path, so the tolerance is derived, not inherited:
   * bf16 keeps 8 significant bits: unit roundoff u = 2^-9.  One product of two rounded operands carries a relative error
     <= 2u + u^2; a K-term contraction with fp32 accumulation is off by at most 2u * sum|a_k b_k| and, for the mixed-sign
     operands here, by about 2u * sqrt(sum (a_k b_k)^2).  Sigmoid / tanh / the convex GRU blend do not amplify it.
-  * Emulating exactly this rounding on the CPU (tests/fused_math.py, ``rnd=bf16_round``) against the fp32 oracle gives
-    max|d hidden| = 1.0e-3 .. 3.2e-3 at max|hidden| = 0.41 .. 1.62, i.e. 1.0 .. 1.3 u of the tensor's scale.
+  * Emulating exactly this rounding on the CPU (tests/fused_math.py, ``rnd=bf16_round, store=bf16_round``) against the fp32
+    oracle gives max|d hidden| of 1 .. 2 u of the tensor's scale.
   TOL_REL = 8 u = 1.5625e-2 of the reference tensor's max magnitude (outputs) / Frobenius norm (gradients) is the stated bar.
 A second, tight bar pins the arithmetic itself: the HIP result must agree with the CPU emulation of the same rounding to
-EMU_TOL = 3e-4 of the tensor's scale (what is left are fp32 summation order and operands that sit on a bf16 rounding boundary).
+EMU_TOL = 1.2e-3 of the tensor's scale (what is left are fp32 summation order and operands that sit on a bf16 rounding boundary).
 """
 import numpy as np
 import pytest
@@ -23,7 +24,7 @@ from test_gpu_model import _synthetic
 pytestmark = pytest.mark.gpu
 BF16_U = 2.0 ** -9
 TOL_REL = 8 * BF16_U
-EMU_TOL = 3e-4
+EMU_TOL = 1.2e-3
 
 
 @pytest.fixture()
@@ -111,21 +112,23 @@ def test_bf16_mode_is_exactly_operand_rounding(bf16_mode, n, e, regions, f, t, o
     ei, ri, rw, x, y, p, mod = _models(R, n, e, regions, f, t, o)
     a, ls = dense_ops(ei, None, ri, rw, n, torch.float32)
     with torch.no_grad():
-        pred_e, hid_e = forward_fused(p, x, a, ls, regional=True, rnd=bf16_round)
+        pred_e, hid_e = forward_fused(p, x, a, ls, regional=True, rnd=bf16_round, store=bf16_round)
         pred_f, hid_f = forward_fused(p, x, a, ls, regional=True)
         pred, hidden = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a_.cuda() for a_ in rw])
     report = []
     for name, got, emu, full in (("pred", pred, pred_e, pred_f), ("hidden", hidden, hid_e, hid_f)):
         scale = float(emu.abs().max())
-        report.append((name, float((got.cpu() - emu).abs().max()) / scale, float((got.cpu() - full).abs().max()) / scale))
-    print("bf16 emulation check (tensor, |hip - emu| / scale, |hip - fp32| / scale):", report)
+        report.append((name, float((got.cpu() - emu).abs().max()) / scale, float((got.cpu() - full).abs().max()) / scale,
+                       float((got.cpu() - emu).pow(2).mean().sqrt() / (got.cpu() - full).pow(2).mean().sqrt())))
+    print("bf16 emulation check (tensor, max|hip - emu| / scale, max|hip - fp32| / scale, rms(hip - emu) / rms(hip - fp32)):", report)
     # hidden: the cell output itself.  (pred is a small difference of large head terms, and the composed (C,F) weights are
     # formed in another fp32 summation order on the GPU: a weight that lands on a bf16 rounding boundary flips for ALL rows
     # at once, which moves pred by as much as the rounding itself -- it is held to the derived tolerance above instead.)
-    name, d_emu, d_full = report[1]
+    name, d_emu, d_full, rms_ratio = report[1]
     assert d_emu <= EMU_TOL, report
+    assert rms_ratio < 0.1, report          # measured 0.015 .. 0.03: 30-60 x closer to the emulation than to fp32
     # the mode is really reduced precision (guards against silently running the fp32 kernels)
-    assert d_full > 2 * EMU_TOL, report
+    assert d_full > 1.5 * EMU_TOL, report
 
 
 def test_bf16_mode_trains(bf16_mode):
