@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libregtgcn_hip.so")
+# REGT_LIB_DIR: a developer build of the same library in another directory (build.py honours the same variable), e.g. the
+# workgroup-trace build of tools/wg_trace.py; never a different implementation
+LIB_PATH = os.path.join(os.environ.get("REGT_LIB_DIR") or os.path.join(HERE, "lib"), "libregtgcn_hip.so")
 ABI_VERSION = 4
 
 f32p = C.POINTER(C.c_float)

@@ -179,7 +179,7 @@ struct Layout {
     float *G0;   // (C, C): the part of d tgnn.linear.weight every region block shares (backward)
     // backward temporaries
     float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
-    float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r), bf16x3 split mode only
+    float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r) for the data-gradient GEMMs
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
     int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
     long slab_floats;
@@ -555,8 +555,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(launch_cell_bwd(a, st));
         if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
     }
-    // The split core takes weights as [N][K] only: give the data gradients transposed copies of the three C x C blocks.
-    const bool split = gemm_mode() != 0;
+    // The three-workgroup cores (gemm_split.h: fp32 planes, bf16x3 split, bf16) take weights as [N][K] only: give the data
+    // gradients transposed copies of the three C x C blocks.  REGT_FP32_CORE=wide keeps the fp32 path on the two-workgroup
+    // core, which reads the weights as they are.
+    const bool split = gemm_mode() != 0 || !fp32_core_wide();
     if (split) {
         PROF("transpose_gate_w", st);
         TRY(launch_transpose3(p.gate_w[2] + C, p.gate_w[0] + C, p.gate_w[1] + C, 3, L.UT, C, C, 2L * C, st));

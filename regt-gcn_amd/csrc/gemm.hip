@@ -16,6 +16,24 @@
 
 namespace regt {
 
+// Developer build (REGT_HIPCC_FLAGS=-DREGT_WG_TRACE, tools/wg_trace.py): the flat GEMM kernels with N == REGT_WG_TRACE_N record,
+// per workgroup, the 100 MHz wall clock at the start of the K loop, at its end and after the epilogue, plus HW_ID / XCC_ID
+// (which CU it ran on) -- the data behind DESIGN.md's "who overlaps with whom on a CU" analysis.
+#ifdef REGT_WG_TRACE
+__device__ long g_wg_trace[4 * WG_TRACE_MAX];
+__device__ long g_wg_marks[8 * WG_TRACE_MAX];
+#define WG_TRACE_T(name) const long name = wall_clock64()
+#define WG_TRACE_END(N, ta, tb)                                                                                              \
+    if (threadIdx.x == 0 && WG_TILE_ID < WG_TRACE_MAX && (N) == REGT_WG_TRACE_N) {                                            \
+        long* q_ = g_wg_trace + 4L * WG_TILE_ID;                                                                              \
+        q_[0] = ta; q_[1] = tb; q_[2] = wall_clock64();                                                                       \
+        q_[3] = ((long)__builtin_amdgcn_s_getreg((31 << 11) | 4)) | ((long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+    }
+#else
+#define WG_TRACE_T(name)
+#define WG_TRACE_END(N, ta, tb)
+#endif
+
 // hipFuncSetAttribute is a (slow, host-synchronous) driver call: do it once per kernel, not per launch.
 template <class K>
 static int set_lds_once(K kernel, int bytes, bool* done) {
@@ -29,6 +47,15 @@ static int set_lds_once(K kernel, int bytes, bool* done) {
 // Each functor has a scalar form (m, c, v) used when the output is not 16-byte tileable (e.g. the
 // (N, O) head output) and a vector form: load() fetches the auxiliary operands of one float4,
 // apply() finishes and stores it (driver: GemmCore::for_each_vec).
+//
+// Straight-line variants (vcol / vload<V> / vapply<V>, drivers: FastCore::for_each_vec, SplitCore::for_each_vec_halves):
+// every decision of the functor that is uniform over a tile (which activation, bf16 or fp32 store, does this column tile
+// hold the r gate, ...) is folded into the compile-time variant V = variant(n0) in [0, NVAR) -- or -1: no specialisation,
+// use load/apply.  For a full tile the driver then runs a body without a single branch.  That is what keeps hipcc's
+// s_waitcnt exact: with per-row `if`s every row of the epilogue became its own basic block and waited vmcnt(0) -- for
+// its own loads AND for the stores of the row before it (stores count on vmcnt on gfx9): a chain of one memory round trip
+// per row, 11 us (two-workgroup core) to 21 us (three-workgroup core) per 128 x 128 tile (tools/wg_trace.py).
+// Column constants (bias) are loaded once per thread (Col), not once per row.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -70,6 +97,21 @@ struct EpiBiasActF {
         st4(e.out + m * e.ldo + c, REGT_V4(F_));
 #undef F_
     }
+    // variants: 0 = none / leaky relu / relu (one select), 1 = sigmoid, 2 = tanh
+    static constexpr int NVAR = 3;
+    struct Col { float4 b; };
+    struct VAux {};
+    struct Tile {};
+    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    __device__ __forceinline__ int variant(int) const { return e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0); }
+    __device__ __forceinline__ Col vcol(int c) const { return Col{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long, int) const { return VAux{}; }
+    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col& col, const VAux&) const {
+        const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
+#define F_(k) (V == 1 ? fast_sigmoid(v.k + col.b.k) : V == 2 ? fast_tanh(v.k + col.b.k) : ((v.k + col.b.k) > 0.f ? (v.k + col.b.k) : (v.k + col.b.k) * ns))
+        st4(e.out + m * e.ldo + c, REGT_V4(F_));
+#undef F_
+    }
 };
 struct EpiGatesF {
     EpiGates e;
@@ -94,6 +136,31 @@ struct EpiGatesF {
         if (c >= e.C) {
             const float4 qv = make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w);
             if (e.q_bf16) st4_bf16(e.q, m * e.C + c - e.C, qv);
+            else st4(e.q + m * e.C + c - e.C, qv);
+        }
+    }
+    // variants: bit 0 = the tile holds r columns (reads h, writes q = r * h), bit 1 = q stored as bf16; tiles are pure z
+    // or pure r when C is a multiple of the tile width
+    static constexpr int NVAR = 4;
+    struct Col { float4 b; };
+    struct VAux { float4 h; };
+    struct Tile {};
+    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    __device__ __forceinline__ int variant(int n0) const { return e.C % GBN ? -1 : (n0 >= e.C ? 1 : 0) + (e.q_bf16 ? 2 : 0); }
+    __device__ __forceinline__ Col vcol(int c) const { return Col{ld4(e.bias + c)}; }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+        VAux a;
+        if (V & 1) a.h = ld4(e.h + m * e.C + c - e.C);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col& col, const VAux& a) const {
+#define F_(k) fast_sigmoid(v.k + col.b.k)
+        const float4 g = REGT_V4(F_);
+#undef F_
+        st4(e.ZR + m * (2L * e.C) + c, g);
+        if (V & 1) {
+            const float4 qv = make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w);
+            if (V & 2) st4_bf16(e.q, m * e.C + c - e.C, qv);
             else st4(e.q + m * e.C + c - e.C, qv);
         }
     }
@@ -130,6 +197,39 @@ struct EpiDgrad1F {
         st4(e.dh + m * e.C + c, REGT_V4(F_));
 #undef F_
     }
+    // variants: bit 0 = dzr stored as bf16
+    static constexpr int NVAR = 2;
+    struct Col {};
+    typedef Aux VAux;
+    struct Tile { long node0; int t0; float invT; };
+    __device__ __forceinline__ Tile vtile(long m0) const {
+        const long node0 = m0 / e.T;
+        return Tile{node0, (int)(m0 - node0 * e.T), 1.0f / (float)e.T};
+    }
+    __device__ __forceinline__ int variant(int) const { return e.dzr_bf16 ? 1 : 0; }
+    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    // node / period of row m0 + r without a 64-bit division per row: once per tile, then (t0 + r) / T on small integers
+    // (the +0.5 keeps the float quotient away from the integer boundaries: exact for t0 + r < 2^16)
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& tl, int r, long m, int c) const {
+        const int x = tl.t0 + r, qd = (int)(((float)x + 0.5f) * tl.invT);
+        const long node = tl.node0 + qd;
+        VAux a;
+        a.p = e.probs[x - qd * e.T];
+        a.h = ld4(e.h + m * e.C + c);
+        a.Z = ld4(e.ZR + m * (2L * e.C) + c);
+        a.R = ld4(e.ZR + m * (2L * e.C) + e.C + c);
+        a.d = ld4(e.dOH + node * e.C + c);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const {
+#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+        if (V & 1) st4_bf16(e.dzr, m * (2L * e.C) + e.C + c, REGT_V4(F_));
+        else st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
+#undef F_
+#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+        st4(e.dh + m * e.C + c, REGT_V4(F_));
+#undef F_
+    }
 };
 struct EpiDgrad2F {
     EpiDgrad2 e;
@@ -149,6 +249,25 @@ struct EpiDgrad2F {
     }
     __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
 #define F_(k) ((a.d.k + v.k) * (a.h.k > 0.f ? 1.0f : e.slope))
+        st4(e.dh + m * e.C + c, REGT_V4(F_));
+#undef F_
+    }
+    // variants: bit 0 = leaky-relu derivative (reads h)
+    static constexpr int NVAR = 2;
+    struct Col {};
+    typedef Aux VAux;
+    struct Tile {};
+    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    __device__ __forceinline__ int variant(int) const { return e.act == ACT_LRELU ? 1 : 0; }
+    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+        VAux a;
+        a.d = ld4(e.dh + m * e.C + c);
+        if (V & 1) a.h = ld4(e.h + m * e.C + c);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const {
+#define F_(k) ((a.d.k + v.k) * ((V & 1) ? (a.h.k > 0.f ? 1.0f : e.slope) : 1.0f))
         st4(e.dh + m * e.C + c, REGT_V4(F_));
 #undef F_
     }
@@ -173,6 +292,22 @@ struct EpiMaskAddF {
         st4(e.out + m * e.ldo + c, REGT_V4(F_));
 #undef F_
     }
+    // variants: bit 0 = an addend is given
+    static constexpr int NVAR = 2;
+    struct Col {};
+    typedef Aux VAux;
+    struct Tile {};
+    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    __device__ __forceinline__ int variant(int) const { return e.add ? 1 : 0; }
+    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+        VAux a;
+        a.mk = ld4(e.mask + m * e.ldm + c);
+        if (V & 1) a.ad = ld4(e.add + m * e.ldadd + c);
+        else a.ad = make_float4(0, 0, 0, 0);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const { apply(m, c, v, a); }
 };
 
 // ---- 8-column-per-thread epilogues (bf16-operand core with bf16 STORAGE of the M x C activations) ------------------------
@@ -347,12 +482,19 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    WG_TRACE_T(t_a);
     core.run(acc, relu_a != 0);
+    WG_TRACE_T(t_b);
     core.for_each_vec(acc, epi);
+    WG_TRACE_END(N, t_a, t_b);
 }
 
-// Split core with the compact LDS layout (two bf16 stages + table, epilogue in two 64-row halves): three workgroups per CU.
-// NP = 3: exact 3-way split (fp32-level accuracy); NP = 1: plain bf16 operands, fp32 accumulate (REGT_GEMM_MODE=bf16).
+// Split core with the compact LDS layout (two stages + table, epilogue in two 64-row halves): three workgroups per CU.
+// NP = 0: fp32 planes on the fp32 MFMA; NP = 3: exact 3-way bf16 split (fp32-level accuracy); NP = 1: plain bf16 operands,
+// fp32 accumulate (REGT_GEMM_MODE=bf16).
+// (Persistent workgroups walking the tiles were tried and measured slower: the turn-around between two tiles of a slot
+// goes from 7 us to 0.6 us, but the three workgroups of a CU then run in step -- all in their K loops, then all in their
+// epilogues -- and the tile loop costs registers; gates GEMM 3.40 ms against 3.19 ms.  DESIGN.md section 6.)
 template <class EpiF, bool REGION, int NP>
 __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -361,7 +503,9 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
     const long m0 = (long)(bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    WG_MARK(6);
     SplitCore<REGION, NP> core(S, rm, n0, N, lds, true);
+    WG_MARK(7);
     core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -370,8 +514,11 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    WG_TRACE_T(t_a);
     core.run(acc, relu_a != 0);
+    WG_TRACE_T(t_b);
     core.for_each_vec_halves(acc, epi);
+    WG_TRACE_END(N, t_a, t_b);
 }
 
 // bf16-operand core + 8-column epilogue (bf16 storage of the activations): same K loop as gemm_flat_split_kernel<.., 1>
@@ -392,8 +539,11 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, lo
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    WG_TRACE_T(t_a);
     core.run(acc, false);
+    WG_TRACE_T(t_b);
     core.for_each_vec8_halves(acc, epi);
+    WG_TRACE_END(N, t_a, t_b);
 }
 
 // Small problems: 64 x 64 tiles (gemm_small.h) -- same operands, segments and epilogues, a quarter of the work per tile.
@@ -427,6 +577,12 @@ int gemm_mode() {
     return g_gemm_mode;
 }
 void set_gemm_mode(int m) { g_gemm_mode = (m == 1 || m == 2) ? m : 0; }
+// REGT_FP32_CORE=wide: fp32 GEMMs on the 2-workgroup-per-CU core (gemm_fast.h) instead of the 3-workgroup one, for A/B timing
+bool fp32_core_wide() {
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("REGT_FP32_CORE"); wide = e && !strcmp(e, "wide") ? 1 : 0; }
+    return wide == 1;
+}
 
 // 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
 static int fast_class(const GemmSegs& S, int N, bool vec) {
@@ -490,10 +646,12 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
         return REGT_OK;
     }
     if constexpr (BT) {
-        if (gemm_mode() != 0) {
+        if (gemm_mode() != 0 || !fp32_core_wide()) {
             const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
             REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-            if (gemm_mode() == 1)
+            if (gemm_mode() == 0)
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 0>), dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, f, relu);
+            else if (gemm_mode() == 1)
                 hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 3>), dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, f, relu);
             else
                 hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 1>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, relu);
@@ -1665,3 +1823,15 @@ int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
 }
 
 }  // namespace regt
+
+#ifdef REGT_WG_TRACE
+// developer build only (not part of include/regtgcn.h): copy the workgroup trace to the host
+extern "C" int regt_wg_trace_read(long* host, long nblocks) {
+    if (nblocks > regt::WG_TRACE_MAX) nblocks = regt::WG_TRACE_MAX;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(regt::g_wg_trace), sizeof(long) * 4 * nblocks);
+}
+extern "C" int regt_wg_marks_read(long* host, long nblocks) {
+    if (nblocks > regt::WG_TRACE_MAX) nblocks = regt::WG_TRACE_MAX;
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(regt::g_wg_marks), sizeof(long) * 8 * nblocks);
+}
+#endif

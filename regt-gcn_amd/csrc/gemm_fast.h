@@ -11,6 +11,7 @@
 //     (an fp32 32x32x2 MFMA occupies the pipe for 64 cycles: plenty of issue slots per gap);
 //   * per-thread row offsets / validity are hoisted out of the loop.
 #pragma once
+#include <type_traits>
 #include "gemm_core.h"
 
 namespace regt {
@@ -73,7 +74,48 @@ __device__ __forceinline__ const int* tile_regions(const GemmSegs& S, const RowM
         }
         red[3] = n;
     }
-    return list;        // valid for thread 0 (the table builder) only
+    return list;        // complete after the caller's next barrier
+}
+
+// Build the iteration table of a tile, one entry per thread: a single thread walking the (segment, repeat, k0) nest took
+// ~6 us per workgroup next to two MFMA-bound waves on its SIMD (tools/wg_trace.py) -- a quarter of the K loop's duration.
+// Every thread walks the <= 3 segments (wave-uniform arithmetic) and the thread whose id falls into a segment's range of
+// slabs writes that slab's descriptor.  Returns the table length; ends with a barrier.
+template <int BMT, bool REGION>
+__device__ __forceinline__ int plan_table(const GemmSegs& S, const RowMap& rm, float* lds, ItDesc* table, int tid) {
+    int* red = reinterpret_cast<int*>(lds);
+    const int* rlist = nullptr;
+    int nreg = 0;
+    if (REGION) {
+        rlist = tile_regions<BMT>(S, rm, red, tid);
+        __syncthreads();
+        nreg = red[3];
+    }
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s < S.nseg) {
+            const GemmSeg& g = S.seg[s];
+            const bool reg = REGION && (g.flags & SEG_REGION);
+            const bool rep = (g.flags & SEG_REPEAT) != 0;
+            const int cnt = reg ? nreg : (rep ? g.nrep : 1);
+            const int nk = (g.K + GBK - 1) / GBK;
+            const int local = tid - n;
+            if (local >= 0 && local < cnt * nk && tid < G_MAX_ITERS) {
+                const int ri = local / nk, r = reg ? rlist[ri] : ri;
+                const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
+                ItDesc d;
+                d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
+                d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
+                d.K = g.K; d.k0 = (local - ri * nk) * GBK; d.region = reg ? r : -1; d.nsplit = g.nsplit;
+                d.abf = (g.flags & SEG_A_BF16) ? 1 : 0; d.pad_ = 0;
+                table[tid] = d;
+            }
+            n += cnt * nk;
+        }
+    }
+    __syncthreads();
+    return n < G_MAX_ITERS ? n : G_MAX_ITERS;
 }
 
 template <bool BT, bool REGION>
@@ -126,37 +168,8 @@ struct FastCore {
         }
     }
 
-    // Build the iteration table (one thread), return its length to everybody.  Ends with a barrier.
-    __device__ __forceinline__ void plan() {
-        int* red = reinterpret_cast<int*>(lds);
-        const int* rlist = nullptr;
-        if (REGION) rlist = tile_regions<GBM>(S, rm, red, tid);
-        if (tid == 0) {
-            int n = 0;
-            const int nreg = REGION ? red[3] : 0;
-            for (int s = 0; s < S.nseg; ++s) {
-                const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
-                const bool reg = REGION && (g.flags & SEG_REGION);
-                const bool rep = (g.flags & SEG_REPEAT) != 0;
-                const int cnt = reg ? nreg : (rep ? g.nrep : 1);
-                for (int ri = 0; ri < cnt; ++ri) {
-                    const int r = reg ? rlist[ri] : ri;
-                    for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
-                        ItDesc d;
-                        const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
-                        d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
-                        d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
-                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit; d.abf = (g.flags & SEG_A_BF16) ? 1 : 0; d.pad_ = 0;
-                        table[n++] = d;
-                    }
-                }
-            }
-            red[2] = n;
-        }
-        __syncthreads();
-        nit = red[2];
-        __syncthreads();
-    }
+    // Build the iteration table (plan_table above).  Ends with a barrier.
+    __device__ __forceinline__ void plan() { nit = plan_table<GBM, REGION>(S, rm, lds, table, tid); }
 
     // Guarded loads as raw buffer loads: the per-tile base goes into a wave-uniform buffer descriptor
     // (SGPRs) and every lane supplies a 32-bit byte offset; a masked-out slot gets an offset beyond
@@ -333,10 +346,69 @@ struct FastCore {
     // rounds as the functor's operand count allows (F::ROUND_ROWS of the thread's 16 rows per round: 16 for one float4 per
     // row, 8 for two to four), and the first round is requested BEFORE the accumulators are staged through LDS, so that
     // its latency overlaps the 64 LDS writes and the barrier.
+    // Full tile + a functor variant: the straight-line body (no row / column guards, no functor branches; see the note on
+    // the functors in gemm.hip).  Rounds of RR rows; when two rounds of auxiliary operands fit the registers the
+    // accumulators free up once they are staged, round g + 1 is requested BEFORE round g is applied, so that its loads
+    // are ahead of round g's stores in the (in-order) vmcnt queue and never wait for a store to complete.
+    template <class F, int V>
+    __device__ __forceinline__ void vec_body(f32x16 (&acc)[2][2], const F& f) const {
+        // one round if the operands of the thread's 16 rows fit 128 registers, else double-buffered rounds of <= 72 each
+        constexpr int AB = (int)sizeof(typename F::VAux);
+        constexpr int RR = AB * 16 <= 512 ? 16 : (AB * 8 <= 288 ? 8 : (AB * 4 <= 288 ? 4 : 2)), NR = 16 / RR;
+        constexpr bool DB = NR > 1;
+        const int c = ecol();
+        const typename F::Tile tl = f.vtile(rm.base);
+        const typename F::Col col = f.vcol(c);
+        typename F::VAux aux[DB ? 2 : 1][RR];
+#pragma unroll
+        for (int j = 0; j < RR; ++j) aux[0][j] = f.template vload<V>(tl, erow(j), rm.base + erow(j), c);
+        stage(acc);
+#pragma unroll
+        for (int g = 0; g < NR; ++g) {
+            if (DB && g + 1 < NR) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const int r = erow(RR * (g + 1) + j);
+                    aux[(g + 1) & 1][j] = f.template vload<V>(tl, r, rm.base + r, c);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                const int r = erow(RR * g + j);
+                f.template vapply<V>(rm.base + r, c, eread(RR * g + j), col, aux[DB ? (g & 1) : 0][j]);
+            }
+            if (!DB && g + 1 < NR) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) {
+                    const int r = erow(RR * (g + 1) + j);
+                    aux[0][j] = f.template vload<V>(tl, r, rm.base + r, c);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    template <class F, int V, class Body>
+    __device__ __forceinline__ static void dispatch_variant(int v, const Body& body) {
+        if constexpr (V < F::NVAR) {
+            if (v == V) body(std::integral_constant<int, V>{});
+            else dispatch_variant<F, V + 1>(v, body);
+        }
+    }
+    // true if the tile is full and the functor has a variant for it (rows m = base + r)
+    template <class F>
+    __device__ __forceinline__ int tile_variant(const F& f) const {
+        const int v = __builtin_amdgcn_readfirstlane(f.variant(n0));
+        return (rm.nvalid == GBM && rm.mul == 1 && n0 + GBN <= N) ? v : -1;
+    }
     template <class F>
     __device__ __forceinline__ void for_each_vec(f32x16 (&acc)[2][2], const F& f) const {
         constexpr int RR = F::ROUND_ROWS;
         static_assert(RR == 4 || RR == 8 || RR == 16, "rows per epilogue round");
+        const int v = tile_variant(f);
+        if (v >= 0) {
+            dispatch_variant<F, 0>(v, [&](auto tag) { vec_body<F, decltype(tag)::value>(acc, f); });
+            return;
+        }
         const int c = ecol();
         typename F::Aux aux[RR];
         if (c < N) {

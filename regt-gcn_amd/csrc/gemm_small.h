@@ -52,36 +52,7 @@ struct SmallCore {
     }
 
     // iteration table: as FastCore::plan
-    __device__ __forceinline__ void plan() {
-        int* red = reinterpret_cast<int*>(lds);
-        const int* rlist = nullptr;
-        if (REGION) rlist = tile_regions<SM_B>(S, rm, red, tid);
-        if (tid == 0) {
-            int n = 0;
-            const int nreg = REGION ? red[3] : 0;
-            for (int s = 0; s < S.nseg; ++s) {
-                const GemmSeg g = s == 0 ? S.seg[0] : (s == 1 ? S.seg[1] : S.seg[2]);
-                const bool reg = REGION && (g.flags & SEG_REGION);
-                const bool rep = (g.flags & SEG_REPEAT) != 0;
-                const int cnt = reg ? nreg : (rep ? g.nrep : 1);
-                for (int ri = 0; ri < cnt; ++ri) {
-                    const int r = reg ? rlist[ri] : ri;
-                    for (int k0 = 0; k0 < g.K && n < G_MAX_ITERS; k0 += GBK) {
-                        ItDesc d;
-                        const long off = (reg || rep) ? (long)r * g.b_region_stride : 0;
-                        d.A = g.A + (rep ? (long)r * g.a_rep_stride : 0);
-                        d.B0 = g.B0 + off; d.B1 = g.B1 + off; d.lda = g.lda; d.ldb = g.ldb;
-                        d.K = g.K; d.k0 = k0; d.region = reg ? r : -1; d.nsplit = g.nsplit; d.abf = 0; d.pad_ = 0;
-                        table[n++] = d;
-                    }
-                }
-            }
-            red[2] = n;
-        }
-        __syncthreads();
-        nit = red[2];
-        __syncthreads();
-    }
+    __device__ __forceinline__ void plan() { nit = plan_table<SM_B, REGION>(S, rm, lds, table, tid); }
 
     struct Srds { __amdgpu_buffer_rsrc_t a, b; int lda, ldb, K, k0, region; };
     __device__ __forceinline__ Srds make_srds(const ItDesc& d) const {

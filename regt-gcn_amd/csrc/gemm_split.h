@@ -22,6 +22,7 @@
 //   * a half's registers are refilled with the same half of the slab after next as soon as they have been stored,
 //     i.e. every global load has two compute blocks of distance.
 #pragma once
+#include <type_traits>
 #include "gemm_fast.h"
 
 namespace regt {
@@ -34,9 +35,16 @@ constexpr int SP_ROW_B = 32;                   // bytes of one (row, plane) of a
 constexpr int SP_PLANE_B = 128 * SP_ROW_B;     // 4096
 // NP = planes per operand: 3 = exact 3-way split (fp32-level accuracy, six partial products), 1 = plain bf16 operands
 // (round-to-nearest-even at staging, ONE product: the "bf16 GEMM inputs, fp32 accumulate" arithmetic of BASELINE configs[4]).
+// NP = 0: no split at all -- the operands stay fp32 (rows of 16 k = 64 B) and the products run on v_mfma_f32_32x32x2_f32:
+// the fp32 arithmetic of FastCore in this core's compact LDS layout and half-slab schedule, i.e. THREE workgroups per CU
+// instead of two (a third workgroup's K loop fills the matrix pipe while another one is in its epilogue).
+constexpr int CP_ROW_B = 64;                   // bytes of one fp32 row of a 16-k half slab: four 16-B k-quads, no pad
+// k-quad g of row r: the quad index is XORed with row bits 2-3, so that the 16 rows a ds_read_b128 / ds_write_b128 service
+// group touches (4 consecutive rows x 4 values of bits 2-3) fall on 16 distinct 16-B bank quads
+__device__ __forceinline__ constexpr int cp_off(int r, int g) { return r * CP_ROW_B + ((g ^ ((r >> 2) & 3)) << 4); }
 template <int NP>
 struct SplitGeom {
-    static constexpr int OPER_B = NP * SP_PLANE_B;       // 12288 / 4096: the planes of one operand
+    static constexpr int OPER_B = NP == 0 ? 128 * CP_ROW_B : NP * SP_PLANE_B;       // 8192 / 12288 / 4096: the planes of one operand
     static constexpr int STAGE_B = 2 * OPER_B;           // A planes, then B planes
     // LDS of a workgroup that stages its epilogue in two 64-row halves (for_each_vec_halves below): the two bf16 stages (or
     // the half-tile epilogue image, whichever is larger), then the iteration table -- 54,528 B (NP = 3: THREE workgroups fit
@@ -122,6 +130,17 @@ struct SplitCore : FastCore<true, REGION> {
     template <bool RELU>
     __device__ __forceinline__ void store_half(int h, const float4 (&ra)[4], const float4 (&rb)[4], int abf = 0) const {
         char* st = reinterpret_cast<char*>(lds) + h * STAGE_B;
+        if constexpr (NP == 0) {       // fp32 rows as they are: one ds_write_b128 per slot
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int off = cp_off((tid >> 2) + 64 * j, tid & 3);
+                float4 a = ra[h + 2 * j];
+                if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                *reinterpret_cast<float4*>(st + off) = a;
+                *reinterpret_cast<float4*>(st + OPER_B + off) = rb[h + 2 * j];
+            }
+            return;
+        }
         if (NP == 1 && abf) *reinterpret_cast<float4*>(st + sp_off(tid >> 1, tid & 1)) = ra[h];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -154,11 +173,25 @@ struct SplitCore : FastCore<true, REGION> {
         for (int j = 0; j < 2; ++j) rb[h + 2 * j] = sload_b(d, h + 2 * j);
     }
     // fragments of half h: NP planes of two 32-row blocks per operand (4 NP x ds_read_b128)
-    struct Frags { bf16x8 a[2][NP], b[2][NP]; };
+    struct FragsB { bf16x8 a[2][NP ? NP : 1], b[2][NP ? NP : 1]; };
+    // NP = 0: [32-row block][k-quad pair kk]: lane half lh holds k = 4 (2 kk + lh) .. + 3 of its row, element j feeds the
+    // MFMA of k-step 4 kk + j (the k order inside a half slab is free as long as A and B agree)
+    struct FragsF { float4 a[2][2], b[2][2]; };
+    using Frags = std::conditional_t<NP == 0, FragsF, FragsB>;
     __device__ __forceinline__ Frags read_frags(int h) const {
         const char* st = reinterpret_cast<const char*>(lds) + h * STAGE_B;
         const int lr = lane & 31, lh = lane >> 5;
         Frags f;
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f.a[t][kk] = *reinterpret_cast<const float4*>(st + cp_off(wr * 64 + t * 32 + lr, 2 * kk + lh));
+                    f.b[t][kk] = *reinterpret_cast<const float4*>(st + OPER_B + cp_off(wc * 64 + t * 32 + lr, 2 * kk + lh));
+                }
+            return f;
+        } else {
 #pragma unroll
         for (int p = NP - 1; p >= 0; --p)        // the last plane of A and plane 0 of B feed the first MFMAs
 #pragma unroll
@@ -167,11 +200,24 @@ struct SplitCore : FastCore<true, REGION> {
                 f.b[t][NP - 1 - p] = *reinterpret_cast<const bf16x8*>(st + OPER_B + (NP - 1 - p) * SP_PLANE_B + sp_off(wc * 64 + t * 32 + lr, lh));
             }
         return f;
+        }
     }
     // acc += A_h x B_h^T over 16 k: NP = 3: 24 MFMAs (6 partial products x 4 tiles, the four accumulators round-robin);
     // NP = 1: 4 MFMAs
     static constexpr int NPROD = NP == 3 ? 6 : 1;
     __device__ __forceinline__ static void mfmas(const Frags& f, f32x16 (&acc)[2][2]) {
+        if constexpr (NP == 0) {     // 8 k-steps x 4 tiles of v_mfma_f32_32x32x2_f32
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(reinterpret_cast<const float*>(&f.a[mt][kk])[j],
+                                                                              reinterpret_cast<const float*>(&f.b[nt][kk])[j], acc[mt][nt], 0, 0, 0);
+        } else {
         constexpr int PA[6] = {NP == 3 ? 2 : 0, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
 #pragma unroll
         for (int q = 0; q < NPROD; ++q)
@@ -180,6 +226,7 @@ struct SplitCore : FastCore<true, REGION> {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mt][PA[q]], f.b[nt][PB[q]], acc[mt][nt], 0, 0, 0);
+        }
     }
     __device__ __forceinline__ void compute(int h, f32x16 (&acc)[2][2]) const { mfmas(read_frags(h), acc); }
 
@@ -197,7 +244,18 @@ struct SplitCore : FastCore<true, REGION> {
         store_half<RELU>(hs, ra, rb, held_abf);
         mfmas(f, acc);
         load_half(hs, next, ra, rb);
-        if (NP == 3) {
+        if (NP == 0) {
+            // 32 MFMAs of 64 pipe cycles each: the 8 fragment reads up front (the first MFMAs need kk = 0 only, but a read
+            // issued late would wait behind the stores), then one LDS write / one global load per MFMA gap
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // VALU | SALU (addresses, relu)
+                if (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
+                else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // VMEM read
+            }
+        } else if (NP == 3) {
             __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);      // all fragment reads
 #pragma unroll
             for (int r = 0; r < 24; ++r) {
@@ -258,10 +316,69 @@ struct SplitCore : FastCore<true, REGION> {
     }
     // Epilogue through LDS in two 64-row halves (the waves with wr == half own those rows): half the image of
     // FastCore::for_each_vec, which is what lets a third workgroup onto the CU.
+    // stage the accumulators of the waves that own 64-row half `half` (between two barriers)
+    __device__ __forceinline__ void stage_half(int half, f32x16 (&acc)[2][2]) const {
+        const int lr = lane & 31, lh = lane >> 5;
+        __syncthreads();
+        if (wr == half) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg)
+                        lds[(mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * G_LDS_KROW + wc * 64 + ni * 32 + lr] = acc[mi][ni][reg];
+        }
+        __syncthreads();
+    }
+    // Straight-line body for a full tile (FastCore::vec_body's counterpart): rounds k = 0 .. NR-1 of RR rows walk half 0,
+    // then half 1; round k + 1 is requested before round k is applied when two rounds of operands fit the registers.
+    template <class F, int V>
+    __device__ __forceinline__ void vec_body_halves(f32x16 (&acc)[2][2], const F& f) const {
+        // (a thread owns 8 rows of each half; two rounds in flight within ~48 registers: 8, 4, 2 or 1 rows per round)
+        constexpr int AB = (int)sizeof(typename F::VAux);
+        constexpr int RR = AB * 8 <= 96 ? 8 : (AB * 4 <= 96 ? 4 : (AB * 2 <= 96 ? 2 : 1)), RPH = 8 / RR, NR = 2 * RPH;
+        constexpr bool DB = true;
+        const int c = Base::ecol();
+        const typename F::Tile tl = f.vtile(rm.base);
+        const typename F::Col col = f.vcol(c);
+        typename F::VAux aux[DB ? 2 : 1][RR];
+        auto request = [&](int k, typename F::VAux (&dst)[RR]) {
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                const int r = (k / RPH) * 64 + (tid >> 5) + 8 * (RR * (k % RPH) + j);
+                dst[j] = f.template vload<V>(tl, r, rm.base + r, c);
+            }
+        };
+        request(0, aux[0]);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            if (k % RPH == 0) {
+                WG_MARK(3 * (k / RPH));
+                stage_half(k / RPH, acc);
+                WG_MARK(3 * (k / RPH) + 1);
+            }
+            if (DB && k + 1 < NR) request(k + 1, aux[(k + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                const int rl = (tid >> 5) + 8 * (RR * (k % RPH) + j), r = (k / RPH) * 64 + rl;
+                f.template vapply<V>(rm.base + r, c, *reinterpret_cast<const float4*>(lds + rl * G_LDS_KROW + 4 * (tid & 31)), col,
+                                     aux[DB ? (k & 1) : 0][j]);
+            }
+            if (!DB && k + 1 < NR) request(k + 1, aux[0]);
+            if (k % RPH == RPH - 1) WG_MARK(3 * (k / RPH) + 2);
+        }
+        __syncthreads();
+    }
     template <class F>
     __device__ __forceinline__ void for_each_vec_halves(f32x16 (&acc)[2][2], const F& f) const {
         constexpr int RR = F::ROUND_ROWS / 2;      // a thread owns 8 rows of each half; half the round of the 256-VGPR cores
         static_assert(RR == 4 || RR == 8, "rows per epilogue round");   // (these kernels are capped at 168 VGPRs: three workgroups per CU)
+        const int v = Base::tile_variant(f);
+        if (v >= 0) {
+            Base::template dispatch_variant<F, 0>(v, [&](auto tag) { vec_body_halves<F, decltype(tag)::value>(acc, f); });
+            return;
+        }
         const int lr = lane & 31, lh = lane >> 5;
         const int c = Base::ecol();
 #pragma unroll
@@ -275,6 +392,7 @@ struct SplitCore : FastCore<true, REGION> {
                     if (r < rm.nvalid) aux[j] = f.load(rm.grow(r), c);
                 }
             }
+            WG_MARK(3 * half);
             __syncthreads();
             if (wr == half) {
 #pragma unroll
@@ -286,6 +404,7 @@ struct SplitCore : FastCore<true, REGION> {
                             lds[(mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh) * G_LDS_KROW + wc * 64 + ni * 32 + lr] = acc[mi][ni][reg];
             }
             __syncthreads();
+            WG_MARK(3 * half + 1);
             if (c < N) {
 #pragma unroll
                 for (int g = 0; g < 8 / RR; ++g) {
@@ -304,6 +423,7 @@ struct SplitCore : FastCore<true, REGION> {
                     }
                 }
             }
+            WG_MARK(3 * half + 2);
         }
         __syncthreads();
     }

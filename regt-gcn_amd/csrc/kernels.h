@@ -4,6 +4,20 @@
 #include "gemm_core.h"
 
 namespace regt {
+// developer build (-DREGT_WG_TRACE, tools/wg_trace.py): per-workgroup wall-clock marks inside the GEMM cores
+#ifdef REGT_WG_TRACE
+#ifndef REGT_WG_TRACE_N
+#define REGT_WG_TRACE_N 512
+#endif
+constexpr int WG_TRACE_MAX = 40000;
+extern __device__ long g_wg_marks[8 * WG_TRACE_MAX];
+// id of the tile at hand: wherever the macros are used, rm / n0 / N name the tile
+#define WG_TILE_ID ((int)(rm.base / 128) * ((N + 127) / 128) + n0 / 128)
+#define WG_MARK(i) do { if (threadIdx.x == 0 && WG_TILE_ID < WG_TRACE_MAX && N == REGT_WG_TRACE_N) g_wg_marks[8L * WG_TILE_ID + (i)] = wall_clock64(); } while (0)
+#else
+#define WG_MARK(i) do { } while (0)
+#endif
+
 
 // ---- epilogue descriptors for the flat segmented GEMM ------------------------------------------
 enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
@@ -159,6 +173,7 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)
 int gemm_mode();
 void set_gemm_mode(int mode);
+bool fp32_core_wide();   // REGT_FP32_CORE=wide (A/B timing of the two fp32 GEMM cores)
 
 int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
                       hipStream_t st);   // dst[b] = src[b]^T, b < count <= 3
