@@ -48,7 +48,7 @@ static int set_lds_once(K kernel, int bytes, bool* done) {
 // (N, O) head output) and a vector form: load() fetches the auxiliary operands of one float4,
 // apply() finishes and stores it (driver: GemmCore::for_each_vec).
 //
-// Straight-line variants (vcol / vload<V> / vapply<V>, drivers: FastCore::for_each_vec, SplitCore::for_each_vec_halves):
+// Straight-line variants (vcol<V> / vtile<V> / vload<V> / vapply<V>, drivers: FastCore::for_each_vec, SplitCore::for_each_vec_halves):
 // every decision of the functor that is uniform over a tile (which activation, bf16 or fp32 store, does this column tile
 // hold the r gate, ...) is folded into the compile-time variant V = variant(n0) in [0, NVAR) -- or -1: no specialisation,
 // use load/apply.  For a full tile the driver then runs a body without a single branch.  That is what keeps hipcc's
@@ -56,6 +56,15 @@ static int set_lds_once(K kernel, int bytes, bool* done) {
 // its own loads AND for the stores of the row before it (stores count on vmcnt on gfx9): a chain of one memory round trip
 // per row, 11 us (two-workgroup core) to 21 us (three-workgroup core) per 128 x 128 tile (tools/wg_trace.py).
 // Column constants (bias) are loaded once per thread (Col), not once per row.
+// Addresses: per array one buffer descriptor for the tile's origin (SGPRs), one per-thread byte offset (vtile) and a
+// wave-uniform row step: loads take it as the instruction's scalar offset (no vector instruction per row goes into their
+// addressing), STORES add it to the vector offset and keep soffset = 0.  A 16-byte buffer store with an SGPR soffset
+// whose data registers the very next VALU instruction overwrites picked up the NEW value now and then on gfx950 (the
+// first dword of a row came out as 1 + e^-x instead of the sigmoid: tests/test_gpu_ops.py::test_linear_sigmoid_rows); the
+// compiler only pads that hazard with a wait state when soffset is an immediate (GCNHazardRecognizer: "this hazard only
+// exists if the instruction is not using a register in the soffset field").  That matters more than it looks: a wave that shares its SIMD with waves streaming MFMAs gets a VALU issue
+// slot only every ~64-200 cycles (tools/micro/valu_under_mfma.hip: 10x slower next to two MFMA-bound waves, whatever its
+// s_setprio), so the epilogue's duration is its VALU instruction count times that, not its memory traffic.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -99,17 +108,20 @@ struct EpiBiasActF {
     }
     // variants: 0 = none / leaky relu / relu (one select), 1 = sigmoid, 2 = tanh
     static constexpr int NVAR = 3;
+    static constexpr bool HAS_ROWTAB = false;
     struct Col { float4 b; };
     struct VAux {};
-    struct Tile {};
-    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    struct Tile { __amdgpu_buffer_rsrc_t out; int v, s; };
     __device__ __forceinline__ int variant(int) const { return e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0); }
-    __device__ __forceinline__ Col vcol(int c) const { return Col{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
-    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long, int) const { return VAux{}; }
-    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col& col, const VAux&) const {
+    template <int V> __device__ __forceinline__ Col vcol(int c) const { return Col{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        return Tile{buf_srd(e.out + g.m0 * e.ldo + g.n0), (g.rr * (int)e.ldo + g.c) * 4, g.step * (int)e.ldo * 4};
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int) const { return VAux{}; }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col& col, const VAux&) const {
         const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
 #define F_(k) (V == 1 ? fast_sigmoid(v.k + col.b.k) : V == 2 ? fast_tanh(v.k + col.b.k) : ((v.k + col.b.k) > 0.f ? (v.k + col.b.k) : (v.k + col.b.k) * ns))
-        st4(e.out + m * e.ldo + c, REGT_V4(F_));
+        buf_st4(t.out, t.v + i * t.s, 0, REGT_V4(F_));
 #undef F_
     }
 };
@@ -140,28 +152,47 @@ struct EpiGatesF {
         }
     }
     // variants: bit 0 = the tile holds r columns (reads h, writes q = r * h), bit 1 = q stored as bf16; tiles are pure z
-    // or pure r when C is a multiple of the tile width
+    // or pure r when C is a multiple of the tile width.  The arithmetic is load()/apply()'s to the bit: the backward pass
+    // forms R (1 - R) from the stored gate, and for a saturated gate one ulp of R is a percent of 1 - R -- a tile must not
+    // round differently from its partial neighbour (folding the bias into the exponent's fma saved a VALU per element
+    // and moved the r-gate gradients by 1 %).
     static constexpr int NVAR = 4;
+    static constexpr bool HAS_ROWTAB = false;
     struct Col { float4 b; };
     struct VAux { float4 h; };
-    struct Tile {};
-    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    struct Tile { __amdgpu_buffer_rsrc_t zr, h, q; int vzr, vh, vq, szr, sh, sq; };
     __device__ __forceinline__ int variant(int n0) const { return e.C % GBN ? -1 : (n0 >= e.C ? 1 : 0) + (e.q_bf16 ? 2 : 0); }
-    __device__ __forceinline__ Col vcol(int c) const { return Col{ld4(e.bias + c)}; }
-    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+    template <int V> __device__ __forceinline__ Col vcol(int c) const { return Col{ld4(e.bias + c)}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.zr = buf_srd(e.ZR + g.m0 * (2L * e.C) + g.n0);
+        t.vzr = (g.rr * 2 * e.C + g.c) * 4;
+        t.szr = g.step * 2 * e.C * 4;
+        if (V & 1) {
+            const long o = g.m0 * e.C + g.n0 - e.C;
+            t.h = buf_srd(e.h + o);
+            t.vh = (g.rr * e.C + g.c) * 4;
+            t.sh = g.step * e.C * 4;
+            t.q = buf_srd((V & 2) ? reinterpret_cast<const char*>(e.q) + 2 * o : reinterpret_cast<const char*>(e.q) + 4 * o);
+            t.vq = (V & 2) ? t.vh >> 1 : t.vh;
+            t.sq = (V & 2) ? t.sh >> 1 : t.sh;
+        }
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
         VAux a;
-        if (V & 1) a.h = ld4(e.h + m * e.C + c - e.C);
+        if (V & 1) a.h = buf_ld4(t.h, t.vh, i * t.sh);
         return a;
     }
-    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col& col, const VAux& a) const {
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col& col, const VAux& a) const {
 #define F_(k) fast_sigmoid(v.k + col.b.k)
         const float4 g = REGT_V4(F_);
 #undef F_
-        st4(e.ZR + m * (2L * e.C) + c, g);
+        buf_st4(t.zr, t.vzr + i * t.szr, 0, g);
         if (V & 1) {
             const float4 qv = make_float4(a.h.x * g.x, a.h.y * g.y, a.h.z * g.z, a.h.w * g.w);
-            if (V & 2) st4_bf16(e.q, m * e.C + c - e.C, qv);
-            else st4(e.q + m * e.C + c - e.C, qv);
+            if (V & 2) buf_st4_bf16(t.q, t.vq + i * t.sq, 0, qv);
+            else buf_st4(t.q, t.vq + i * t.sq, 0, qv);
         }
     }
 };
@@ -197,37 +228,55 @@ struct EpiDgrad1F {
         st4(e.dh + m * e.C + c, REGT_V4(F_));
 #undef F_
     }
-    // variants: bit 0 = dzr stored as bf16
+    // variants: bit 0 = dzr stored as bf16.  The row -> (node, period) map needs an integer division: it is done once
+    // per tile row (vrow, 128 threads, kept in LDS) instead of once per row slot of every thread.
     static constexpr int NVAR = 2;
+    static constexpr bool HAS_ROWTAB = true;
     struct Col {};
-    typedef Aux VAux;
-    struct Tile { long node0; int t0; float invT; };
-    __device__ __forceinline__ Tile vtile(long m0) const {
-        const long node0 = m0 / e.T;
-        return Tile{node0, (int)(m0 - node0 * e.T), 1.0f / (float)e.T};
-    }
+    struct Tile { __amdgpu_buffer_rsrc_t h, zr, d, dzr, dh; int vc, vzr, sc, szr, vd, vdzr, sdzr, rstep; const EpiRowEnt* rt; };
     __device__ __forceinline__ int variant(int) const { return e.dzr_bf16 ? 1 : 0; }
-    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
-    // node / period of row m0 + r without a 64-bit division per row: once per tile, then (t0 + r) / T on small integers
-    // (the +0.5 keeps the float quotient away from the integer boundaries: exact for t0 + r < 2^16)
-    template <int V> __device__ __forceinline__ VAux vload(const Tile& tl, int r, long m, int c) const {
-        const int x = tl.t0 + r, qd = (int)(((float)x + 0.5f) * tl.invT);
-        const long node = tl.node0 + qd;
+    __device__ __forceinline__ EpiRowEnt vrow(long m) const {
+        const long node = m / e.T;
+        return EpiRowEnt{(int)(node * e.C * 4), e.probs[(int)(m - node * e.T)]};
+    }
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.h = buf_srd(e.h + g.m0 * e.C + g.n0);
+        t.dh = buf_srd(e.dh + g.m0 * e.C + g.n0);
+        t.zr = buf_srd(e.ZR + g.m0 * (2L * e.C) + g.n0);
+        t.d = buf_srd(e.dOH + g.n0);
+        const long o = g.m0 * (2L * e.C) + e.C + g.n0;
+        t.dzr = buf_srd((V & 1) ? reinterpret_cast<const char*>(e.dzr) + 2 * o : reinterpret_cast<const char*>(e.dzr) + 4 * o);
+        t.vc = (g.rr * e.C + g.c) * 4;
+        t.sc = g.step * e.C * 4;
+        t.vzr = 2 * t.vc - g.c * 4;
+        t.szr = 2 * t.sc;
+        t.vd = g.c * 4;
+        t.vdzr = (V & 1) ? t.vzr >> 1 : t.vzr;
+        t.sdzr = (V & 1) ? t.szr >> 1 : t.szr;
+        t.rt = g.rowtab + g.rr;
+        t.rstep = g.step;
+        return t;
+    }
+    struct VAux { float4 h, Z, R, d; float p; };
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
+        const EpiRowEnt re = t.rt[i * t.rstep];
         VAux a;
-        a.p = e.probs[x - qd * e.T];
-        a.h = ld4(e.h + m * e.C + c);
-        a.Z = ld4(e.ZR + m * (2L * e.C) + c);
-        a.R = ld4(e.ZR + m * (2L * e.C) + e.C + c);
-        a.d = ld4(e.dOH + node * e.C + c);
+        a.p = re.p;
+        a.h = buf_ld4(t.h, t.vc, i * t.sc);
+        a.Z = buf_ld4(t.zr, t.vzr, i * t.szr);
+        a.R = buf_ld4(t.zr, t.vzr, i * t.szr + e.C * 4);
+        a.d = buf_ld4(t.d, t.vd + re.off, 0);
         return a;
     }
-    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const {
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
 #define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
-        if (V & 1) st4_bf16(e.dzr, m * (2L * e.C) + e.C + c, REGT_V4(F_));
-        else st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
+        if (V & 1) buf_st4_bf16(t.dzr, t.vdzr + i * t.sdzr, 0, REGT_V4(F_));
+        else buf_st4(t.dzr, t.vdzr + i * t.sdzr, 0, REGT_V4(F_));
 #undef F_
 #define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
-        st4(e.dh + m * e.C + c, REGT_V4(F_));
+        buf_st4(t.dh, t.vc + i * t.sc, 0, REGT_V4(F_));
 #undef F_
     }
 };
@@ -254,21 +303,29 @@ struct EpiDgrad2F {
     }
     // variants: bit 0 = leaky-relu derivative (reads h)
     static constexpr int NVAR = 2;
+    static constexpr bool HAS_ROWTAB = false;
     struct Col {};
-    typedef Aux VAux;
-    struct Tile {};
-    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    struct VAux { float4 d, h; };
+    struct Tile { __amdgpu_buffer_rsrc_t dh, h; int v, s; };
     __device__ __forceinline__ int variant(int) const { return e.act == ACT_LRELU ? 1 : 0; }
-    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
-    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.dh = buf_srd(e.dh + g.m0 * e.C + g.n0);
+        if (V & 1) t.h = buf_srd(e.h + g.m0 * e.C + g.n0);
+        t.v = (g.rr * e.C + g.c) * 4;
+        t.s = g.step * e.C * 4;
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
         VAux a;
-        a.d = ld4(e.dh + m * e.C + c);
-        if (V & 1) a.h = ld4(e.h + m * e.C + c);
+        a.d = buf_ld4(t.dh, t.v, i * t.s);
+        if (V & 1) a.h = buf_ld4(t.h, t.v, i * t.s);
         return a;
     }
-    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const {
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
 #define F_(k) ((a.d.k + v.k) * ((V & 1) ? (a.h.k > 0.f ? 1.0f : e.slope) : 1.0f))
-        st4(e.dh + m * e.C + c, REGT_V4(F_));
+        buf_st4(t.dh, t.v + i * t.s, 0, REGT_V4(F_));
 #undef F_
     }
 };
@@ -294,20 +351,33 @@ struct EpiMaskAddF {
     }
     // variants: bit 0 = an addend is given
     static constexpr int NVAR = 2;
+    static constexpr bool HAS_ROWTAB = false;
     struct Col {};
-    typedef Aux VAux;
-    struct Tile {};
-    __device__ __forceinline__ Tile vtile(long) const { return Tile{}; }
+    struct VAux { float4 mk, ad; };
+    struct Tile { __amdgpu_buffer_rsrc_t out, mask, add; int vo, vm, va, so, sm, sa; };
     __device__ __forceinline__ int variant(int) const { return e.add ? 1 : 0; }
-    __device__ __forceinline__ Col vcol(int) const { return Col{}; }
-    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int, long m, int c) const {
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.out = buf_srd(e.out + g.m0 * e.ldo + g.n0);
+        t.mask = buf_srd(e.mask + g.m0 * e.ldm + g.n0);
+        if (V & 1) t.add = buf_srd(e.add + g.m0 * e.ldadd + g.n0);
+        t.vo = (g.rr * (int)e.ldo + g.c) * 4; t.so = g.step * (int)e.ldo * 4;
+        t.vm = (g.rr * (int)e.ldm + g.c) * 4; t.sm = g.step * (int)e.ldm * 4;
+        t.va = (g.rr * (int)e.ldadd + g.c) * 4; t.sa = g.step * (int)e.ldadd * 4;
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
         VAux a;
-        a.mk = ld4(e.mask + m * e.ldm + c);
-        if (V & 1) a.ad = ld4(e.add + m * e.ldadd + c);
-        else a.ad = make_float4(0, 0, 0, 0);
+        a.mk = buf_ld4(t.mask, t.vm, i * t.sm);
+        a.ad = (V & 1) ? buf_ld4(t.add, t.va, i * t.sa) : make_float4(0, 0, 0, 0);
         return a;
     }
-    template <int V> __device__ __forceinline__ void vapply(long m, int c, float4 v, const Col&, const VAux& a) const { apply(m, c, v, a); }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
+#define F_(k) ((a.mk.k > 0.f ? v.k : 0.f) + a.ad.k)
+        buf_st4(t.out, t.vo + i * t.so, 0, REGT_V4(F_));
+#undef F_
+    }
 };
 
 // ---- 8-column-per-thread epilogues (bf16-operand core with bf16 STORAGE of the M x C activations) ------------------------
@@ -474,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
     Core core(S, rm, n0, N, lds);
+    core.fill_rowtab(epi);
     core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -496,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void gemm_flat_fast_kernel(GemmSegs S, long
 // goes from 7 us to 0.6 us, but the three workgroups of a CU then run in step -- all in their K loops, then all in their
 // epilogues -- and the tile loop costs registers; gates GEMM 3.40 ms against 3.19 ms.  DESIGN.md section 6.)
 template <class EpiF, bool REGION, int NP>
-__global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a) {
+__global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, long M, int N, EpiF epi, int relu_a, int uniform) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -506,7 +577,9 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
     WG_MARK(6);
     SplitCore<REGION, NP> core(S, rm, n0, N, lds, true);
     WG_MARK(7);
-    core.plan();
+    core.fill_rowtab(epi);
+    const bool uni = !REGION && uniform != 0;      // scalar slab descriptors (host: uniform_ok): no iteration table
+    if (!uni) core.plan();
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -515,7 +588,8 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     WG_TRACE_T(t_a);
-    core.run(acc, relu_a != 0);
+    if (uni) core.run_uniform(acc, relu_a != 0);
+    else core.run(acc, relu_a != 0);
     WG_TRACE_T(t_b);
     core.for_each_vec_halves(acc, epi);
     WG_TRACE_END(N, t_a, t_b);
@@ -584,6 +658,21 @@ bool fp32_core_wide() {
     return wide == 1;
 }
 
+// the K loop may keep its slab descriptors in scalar registers (SplitCore::run_u): no region-masked segment, every K a
+// multiple of the 32-k slab, byte offsets of a tile's rows within 31 bits.  REGT_GEMM_DESC=table forces the LDS table.
+static int uniform_ok(const GemmSegs& S, long M) {
+    static int force_table = -1;
+    if (force_table < 0) { const char* e = getenv("REGT_GEMM_DESC"); force_table = e && !strcmp(e, "table") ? 1 : 0; }
+    if (force_table) return 0;
+    for (int s = 0; s < S.nseg; ++s) {
+        const GemmSeg& g = S.seg[s];
+        if ((g.flags & SEG_REGION) || g.K % GBK != 0 || g.K <= 0) return 0;
+        if (g.lda * 4 * (GBM + 1) >= (1L << 31) || g.ldb * 4 * (GBN + 1) >= (1L << 31)) return 0;
+    }
+    (void)M;
+    return 1;
+}
+
 // 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
 static int fast_class(const GemmSegs& S, int N, bool vec) {
     if (!vec || N % 4 != 0 || S.nseg < 1) return -1;
@@ -650,11 +739,11 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
             const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
             REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
             if (gemm_mode() == 0)
-                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 0>), dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, f, relu);
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 0>), dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, f, relu, uniform_ok(S, M));
             else if (gemm_mode() == 1)
-                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 3>), dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, f, relu);
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 3>), dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, f, relu, uniform_ok(S, M));
             else
-                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 1>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, relu);
+                hipLaunchKernelGGL((gemm_flat_split_kernel<EpiF, REGION, 1>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, relu, uniform_ok(S, M));
             REGT_CHECK_LAUNCH();
             return REGT_OK;
         }

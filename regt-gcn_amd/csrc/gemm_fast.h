@@ -16,7 +16,7 @@
 
 namespace regt {
 
-constexpr int G_MAX_ITERS = 96;   // descriptor table capacity (e.g. K=512 in 3 segments with region repeats)
+constexpr int G_MAX_ITERS = 80;   // descriptor table capacity (e.g. K=512 in 3 segments with region repeats)
 
 struct ItDesc {
     const float* A;
@@ -26,7 +26,8 @@ struct ItDesc {
     int K, k0, region, nsplit;
     int abf, pad_;        // A operand stored as bf16 (SEG_A_BF16)
 };
-constexpr int G_TABLE_BYTES = G_MAX_ITERS * (int)sizeof(ItDesc);
+// the iteration table, then the epilogue's row table (EpiRowEnt per tile row, functors with HAS_ROWTAB)
+constexpr int G_TABLE_BYTES = G_MAX_ITERS * (int)sizeof(ItDesc) + EPI_ROWTAB_BYTES;
 constexpr int G_FAST_LDS_BYTES = G_LDS_BYTES + G_TABLE_BYTES;
 
 // Sorted list of the DISTINCT regions among a tile's rows, built by thread 0 in LDS (red[8 ..): region of each row, then the
@@ -350,40 +351,35 @@ struct FastCore {
     // the functors in gemm.hip).  Rounds of RR rows; when two rounds of auxiliary operands fit the registers the
     // accumulators free up once they are staged, round g + 1 is requested BEFORE round g is applied, so that its loads
     // are ahead of round g's stores in the (in-order) vmcnt queue and never wait for a store to complete.
+    __device__ __forceinline__ EpiRowEnt* rowtab() const { return reinterpret_cast<EpiRowEnt*>(table + G_MAX_ITERS); }
+    // fill the row table of a functor that wants one (before a barrier that precedes the epilogue, e.g. plan()'s)
+    template <class F>
+    __device__ __forceinline__ void fill_rowtab(const F& f) const {
+        if constexpr (F::HAS_ROWTAB) {
+            if (tid < GBM) rowtab()[tid] = f.vrow(rm.base + (tid < rm.nvalid ? tid : 0));
+        }
+    }
     template <class F, int V>
     __device__ __forceinline__ void vec_body(f32x16 (&acc)[2][2], const F& f) const {
         // one round if the operands of the thread's 16 rows fit 128 registers, else double-buffered rounds of <= 72 each
         constexpr int AB = (int)sizeof(typename F::VAux);
         constexpr int RR = AB * 16 <= 512 ? 16 : (AB * 8 <= 288 ? 8 : (AB * 4 <= 288 ? 4 : 2)), NR = 16 / RR;
         constexpr bool DB = NR > 1;
-        const int c = ecol();
-        const typename F::Tile tl = f.vtile(rm.base);
-        const typename F::Col col = f.vcol(c);
+        const EpiGeom geo{rm.base, n0, tid >> 5, 4 * (tid & 31), 8, rowtab()};
+        const typename F::Tile tl = f.template vtile<V>(geo);
+        const typename F::Col col = f.template vcol<V>(ecol());
         typename F::VAux aux[DB ? 2 : 1][RR];
 #pragma unroll
-        for (int j = 0; j < RR; ++j) aux[0][j] = f.template vload<V>(tl, erow(j), rm.base + erow(j), c);
+        for (int j = 0; j < RR; ++j) aux[0][j] = f.template vload<V>(tl, j);
         stage(acc);
 #pragma unroll
         for (int g = 0; g < NR; ++g) {
             if (DB && g + 1 < NR) {
 #pragma unroll
-                for (int j = 0; j < RR; ++j) {
-                    const int r = erow(RR * (g + 1) + j);
-                    aux[(g + 1) & 1][j] = f.template vload<V>(tl, r, rm.base + r, c);
-                }
+                for (int j = 0; j < RR; ++j) aux[(g + 1) & 1][j] = f.template vload<V>(tl, RR * (g + 1) + j);
             }
 #pragma unroll
-            for (int j = 0; j < RR; ++j) {
-                const int r = erow(RR * g + j);
-                f.template vapply<V>(rm.base + r, c, eread(RR * g + j), col, aux[DB ? (g & 1) : 0][j]);
-            }
-            if (!DB && g + 1 < NR) {
-#pragma unroll
-                for (int j = 0; j < RR; ++j) {
-                    const int r = erow(RR * (g + 1) + j);
-                    aux[0][j] = f.template vload<V>(tl, r, rm.base + r, c);
-                }
-            }
+            for (int j = 0; j < RR; ++j) f.template vapply<V>(tl, RR * g + j, eread(RR * g + j), col, aux[DB ? (g & 1) : 0][j]);
         }
         __syncthreads();
     }
@@ -397,6 +393,9 @@ struct FastCore {
     // true if the tile is full and the functor has a variant for it (rows m = base + r)
     template <class F>
     __device__ __forceinline__ int tile_variant(const F& f) const {
+#ifdef REGT_EPI_GENERIC      // developer switch: every tile through the guarded load()/apply() path (A/B checks of the variants)
+        return -1;
+#endif
         const int v = __builtin_amdgcn_readfirstlane(f.variant(n0));
         return (rm.nvalid == GBM && rm.mul == 1 && n0 + GBN <= N) ? v : -1;
     }

@@ -172,6 +172,111 @@ struct SplitCore : FastCore<true, REGION> {
 #pragma unroll
         for (int j = 0; j < 2; ++j) rb[h + 2 * j] = sload_b(d, h + 2 * j);
     }
+    // ---- scalar slab descriptors ("uniform" path) ---------------------------------------------------------------------
+    // VALU instructions are not free next to MFMAs: on this hardware they share the SIMD's vector issue, every vector
+    // instruction of any wave of the SIMD takes ~7 cycles away from the matrix pipe (tools/micro/mfma_valu_mix.hip: one
+    // VALU per fp32 MFMA costs 10 % of the MFMA rate).  The table path above spends ~28 of them per 16-k half slab (15
+    // v_readfirstlane to get a descriptor out of LDS, 64-bit address arithmetic, per-load guards and selects).  Here the
+    // walk over (segment, repeat, k0) and the descriptors stay in scalar registers, computed by the scalar unit from
+    // the kernel arguments: the base pointer of the tile's rows, num_records = the bytes of the VALID rows (rows past the
+    // end return 0 through the range check: no per-load guard), the slab's k offset as the instruction's scalar offset;
+    // what is left per slab are four v_mad for the per-thread row offsets.  Requirements (host: uniform_ok in gemm.hip):
+    // no region-masked segment, every K a multiple of 32, rows of a tile consecutive (rm.mul == 1).
+    struct SegCursor { int s, ri, k0; };
+    __device__ __forceinline__ const GemmSeg& cseg(int sidx) const { return S.seg[sidx]; }
+    __device__ __forceinline__ int total_slabs() const {
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < S.nseg) n += ((S.seg[q].flags & SEG_REPEAT) ? S.seg[q].nrep : 1) * (S.seg[q].K / GBK);
+        return n;
+    }
+    __device__ __forceinline__ void cursor_next(SegCursor& c) const {
+        const GemmSeg& g = cseg(c.s);
+        c.k0 += GBK;
+        if (c.k0 >= g.K) {
+            c.k0 = 0;
+            if (++c.ri >= ((g.flags & SEG_REPEAT) ? g.nrep : 1)) { c.ri = 0; ++c.s; }
+        }
+    }
+    struct SrdsU { __amdgpu_buffer_rsrc_t a, b; int abf, va[2], vb[2], sa, sb; };
+    __device__ __forceinline__ SrdsU make_u(const SegCursor& c, bool live) const {
+        const GemmSeg& g = cseg(live ? c.s : 0);
+        const bool rep = (g.flags & SEG_REPEAT) != 0;
+        SrdsU d;
+        d.abf = (g.flags & SEG_A_BF16) ? 1 : 0;
+        const int lda_b = (int)g.lda * (d.abf ? 2 : 4), ldb_b = (int)g.ldb * 4;
+        const char* ap = reinterpret_cast<const char*>(g.A) + (rep ? (long)c.ri * g.a_rep_stride * 4 : 0) + rm.base * lda_b;
+        const long boff = rep ? (long)c.ri * g.b_region_stride : 0;
+        const bool lowb = n0 < g.nsplit;
+        const float* bp = lowb ? g.B0 + boff + (long)n0 * g.ldb : g.B1 + boff + (long)(n0 - g.nsplit) * g.ldb;
+        const int blim = (lowb && g.nsplit < N ? g.nsplit : N) - n0, brows = blim < GBN ? blim : GBN;
+        d.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ap), 0, live ? rm.nvalid * lda_b : 0, 0x00020000);
+        d.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp), 0, live ? brows * ldb_b : 0, 0x00020000);
+        if (NP == 1 && d.abf) {
+            d.va[0] = (tid >> 1) * lda_b + (tid & 1) * 16;
+            d.va[1] = 0;
+        } else {
+            d.va[0] = (tid >> 2) * lda_b + (tid & 3) * 16;
+            d.va[1] = d.va[0] + 64 * lda_b;
+        }
+        d.vb[0] = (tid >> 2) * ldb_b + (tid & 3) * 16;
+        d.vb[1] = d.vb[0] + 64 * ldb_b;
+        d.sa = c.k0 * (d.abf ? 2 : 4);
+        d.sb = c.k0 * 4;
+        return d;
+    }
+    __device__ __forceinline__ void load_half(int h, const SrdsU& d, float4 (&ra)[4], float4 (&rb)[4]) const {
+        if (NP == 1 && d.abf) {
+            ra[h] = buf_ld4(d.a, d.va[0], d.sa + 32 * h);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[h + 2 * j] = buf_ld4(d.a, d.va[j], d.sa + 64 * h);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rb[h + 2 * j] = buf_ld4(d.b, d.vb[j], d.sb + 64 * h);
+    }
+    // the schedule of run_t with scalar descriptors
+    template <bool RELU>
+    __device__ __forceinline__ void run_u(f32x16 (&acc)[2][2]) const {
+        const int nslab = total_slabs();
+        if (nslab == 0) return;
+        float4 ra[4], rb[4];
+        int held;
+        SegCursor c{0, 0, 0};
+        {
+            const SrdsU d = make_u(c, true);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+            held = d.abf;
+        }
+        store_half<RELU>(0, ra, rb, held);
+        store_half<RELU>(1, ra, rb, held);
+        {
+            const bool two = nslab > 1;
+            if (two) cursor_next(c);
+            const SrdsU d = make_u(c, two);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+            held = d.abf;
+        }
+        __syncthreads();
+        compute(0, acc);
+        for (int it = 0; it + 1 < nslab; ++it) {
+            const bool live = it + 2 < nslab;
+            if (live) cursor_next(c);
+            const SrdsU nx = make_u(c, live);
+            __syncthreads();
+            fused<RELU>(0, 1, nx, ra, rb, acc, held);
+            __syncthreads();
+            fused<RELU>(1, 0, nx, ra, rb, acc, held);
+            held = nx.abf;
+        }
+        __syncthreads();
+        compute(1, acc);
+        __syncthreads();
+    }
+
     // fragments of half h: NP planes of two 32-row blocks per operand (4 NP x ds_read_b128)
     struct FragsB { bf16x8 a[2][NP ? NP : 1], b[2][NP ? NP : 1]; };
     // NP = 0: [32-row block][k-quad pair kk]: lane half lh holds k = 4 (2 kk + lh) .. + 3 of its row, element j feeds the
@@ -234,8 +339,8 @@ struct SplitCore : FastCore<true, REGION> {
     // conversion VALU ops and now and then a plane write, so that a single wave keeps its SIMD's matrix pipe busy (a
     // bf16 32x32x16 MFMA occupies the pipe for 32 cycles = 8 issue slots).  The registers just stored are refilled
     // with the same half of the slab after next.
-    template <bool RELU>
-    __device__ __forceinline__ void fused(int hs, int hc, const Srds& next, float4 (&ra)[4], float4 (&rb)[4], f32x16 (&acc)[2][2],
+    template <bool RELU, class D>
+    __device__ __forceinline__ void fused(int hs, int hc, const D& next, float4 (&ra)[4], float4 (&rb)[4], f32x16 (&acc)[2][2],
                                           int held_abf) const {
         __builtin_amdgcn_sched_barrier(0);       // the interleaving pattern below applies to this block only
         // fragment reads first in program order: the LDS writes below cannot be proven disjoint from them and would
@@ -338,19 +443,12 @@ struct SplitCore : FastCore<true, REGION> {
         // (a thread owns 8 rows of each half; two rounds in flight within ~48 registers: 8, 4, 2 or 1 rows per round)
         constexpr int AB = (int)sizeof(typename F::VAux);
         constexpr int RR = AB * 8 <= 96 ? 8 : (AB * 4 <= 96 ? 4 : (AB * 2 <= 96 ? 2 : 1)), RPH = 8 / RR, NR = 2 * RPH;
-        constexpr bool DB = true;
-        const int c = Base::ecol();
-        const typename F::Tile tl = f.vtile(rm.base);
-        const typename F::Col col = f.vcol(c);
-        typename F::VAux aux[DB ? 2 : 1][RR];
-        auto request = [&](int k, typename F::VAux (&dst)[RR]) {
+        const EpiGeom geo{rm.base, n0, tid >> 5, 4 * (tid & 31), 8, Base::rowtab()};
+        const typename F::Tile tl = f.template vtile<V>(geo);
+        const typename F::Col col = f.template vcol<V>(Base::ecol());
+        typename F::VAux aux[2][RR];
 #pragma unroll
-            for (int j = 0; j < RR; ++j) {
-                const int r = (k / RPH) * 64 + (tid >> 5) + 8 * (RR * (k % RPH) + j);
-                dst[j] = f.template vload<V>(tl, r, rm.base + r, c);
-            }
-        };
-        request(0, aux[0]);
+        for (int j = 0; j < RR; ++j) aux[0][j] = f.template vload<V>(tl, j);
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             if (k % RPH == 0) {
@@ -358,14 +456,16 @@ struct SplitCore : FastCore<true, REGION> {
                 stage_half(k / RPH, acc);
                 WG_MARK(3 * (k / RPH) + 1);
             }
-            if (DB && k + 1 < NR) request(k + 1, aux[(k + 1) & 1]);
+            if (k + 1 < NR) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) aux[(k + 1) & 1][j] = f.template vload<V>(tl, RR * (k + 1) + j);
+            }
 #pragma unroll
             for (int j = 0; j < RR; ++j) {
-                const int rl = (tid >> 5) + 8 * (RR * (k % RPH) + j), r = (k / RPH) * 64 + rl;
-                f.template vapply<V>(rm.base + r, c, *reinterpret_cast<const float4*>(lds + rl * G_LDS_KROW + 4 * (tid & 31)), col,
-                                     aux[DB ? (k & 1) : 0][j]);
+                const int i = RR * k + j;         // row slot: row (tid >> 5) + 8 i; inside its half: slot i & 7
+                f.template vapply<V>(tl, i, *reinterpret_cast<const float4*>(lds + ((tid >> 5) + 8 * (i & 7)) * G_LDS_KROW + 4 * (tid & 31)),
+                                     col, aux[k & 1][j]);
             }
-            if (!DB && k + 1 < NR) request(k + 1, aux[0]);
             if (k % RPH == RPH - 1) WG_MARK(3 * (k / RPH) + 2);
         }
         __syncthreads();
@@ -488,6 +588,11 @@ struct SplitCore : FastCore<true, REGION> {
         if (nit == 0) return;
         if (relu_a) run_t<true>(acc);            // head only: relu on A while staging
         else run_t<false>(acc);
+    }
+    // scalar-descriptor path (no iteration table: plan() is not needed); host-checked eligibility
+    __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) const {
+        if (relu_a) run_u<true>(acc);
+        else run_u<false>(acc);
     }
 };
 

@@ -18,6 +18,40 @@ extern __device__ long g_wg_marks[8 * WG_TRACE_MAX];
 #define WG_MARK(i) do { } while (0)
 #endif
 
+// ---- buffer-descriptor addressing for the straight-line epilogues (gemm.hip functors) ----------------------------------
+// One descriptor per array and tile (its base is the tile's origin, wave-uniform), a per-thread byte offset and a
+// wave-uniform scalar offset per row slot: no vector instruction is spent on addresses inside the row loops.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_srd(const void* p) {      // p must be wave-uniform
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, int voff, int soff, float4 v) {
+    const u32x4_t w = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, soff, 0);
+}
+// four fp32 -> four bf16 (round to nearest even), one 8-byte store
+__device__ __forceinline__ void buf_st4_bf16(__amdgpu_buffer_rsrc_t r, int voff, int soff, float4 v) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = {v.x, v.y}, hi = {v.z, v.w};
+    const u32x2_t w = {__builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_t)),
+                       __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+}
+// per tile row: byte offset of the row's node in an (N, C) fp32 array and its period's attention probability (EpiDgrad1F)
+struct EpiRowEnt { int off; float p; };
+// where a thread sits in the epilogue of a full tile: rows rr + step * i (i = row slot), columns c .. of the tile at (m0, n0)
+struct EpiGeom { long m0; int n0, rr, c, step; const EpiRowEnt* rowtab; };
+constexpr int EPI_ROWTAB_BYTES = 128 * (int)sizeof(EpiRowEnt);
+
 
 // ---- epilogue descriptors for the flat segmented GEMM ------------------------------------------
 enum : int { ACT_NONE = 0, ACT_LRELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };

@@ -157,6 +157,35 @@ def test_linear_matches_torch_fp32(R, m, k, n, act):
     assert float((got.double() - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("act", [0, 1, 3, 4])
+def test_linear_full_tiles_every_row_every_run(R, mode, act):
+    """Many full 128 x 128 tiles next to a partial row tile, repeated: the branch-free epilogue of full tiles (buffer stores,
+    one per thread and row slot) must give every element, every time.  A 16-byte buffer store with an SGPR soffset whose
+    data registers the next VALU instruction reused came out with that instruction's value now and then on gfx950 (first
+    dword of a row = 1 + e^-x instead of sigmoid(x)); the stores now carry the row offset in the vector offset."""
+    lib = R.load_library()
+    lib.regt_set_gemm_mode(mode)
+    try:
+        g = torch.Generator().manual_seed(7 + act)
+        m, n, k = 36000, 256, 64
+        a = torch.randn(m, k, generator=g).cuda()
+        w = (torch.randn(n, k, generator=g) * 0.1).cuda()
+        b = torch.randn(n, generator=g).cuda()
+        z = a.double() @ w.double().t() + b.double()
+        want = {0: z, 1: torch.nn.functional.leaky_relu(z, 0.01), 3: torch.sigmoid(z), 4: torch.tanh(z)}[act].float()
+        first = None
+        for _ in range(5):
+            got = R.ops.linear(a, w, b, act)
+            assert float((got - want).abs().max()) < 2e-5
+            if first is None:
+                first = got.clone()
+            else:
+                assert torch.equal(got, first)
+    finally:
+        lib.regt_set_gemm_mode(0)
+
+
 def test_linear_asymmetric_identity(R):
     # A = I with an asymmetric weight catches a transposed C write (cdna guide section 3)
     k = 64
