@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float csum = 0.f;
+    f32x2 csum2 = {0.f, 0.f};
 
     // Both operands stream through wave-uniform buffer descriptors based at the chunk's first row
     // (vector path: ldp/ldq multiples of 4 and 16-B aligned bases, checked on the host).
@@ -1158,38 +1158,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     // 8 KB = two 16-byte loads per thread (8 columns each), widened to fp32 on the way into LDS -- this kernel's arithmetic
     // stays the fp32 MFMA
     const bool second = a.Q2 != nullptr && j0 >= a.nin_split;          // this column tile reads the second operand
-    const __amdgpu_buffer_rsrc_t sp = Core::make_srd(reinterpret_cast<const float*>(
-        reinterpret_cast<const char*>(a.P) + (PBF ? 2 : 4) * (r0 * a.ldp + i0)));
-    const __amdgpu_buffer_rsrc_t sq = second ? Core::make_srd(a.Q2 + r0 * a.ldq2 + (j0 - a.nin_split)) : Core::make_srd(a.Q + r0 * a.ldq + j0);
     const int ldp = (int)a.ldp, ldq = second ? (int)a.ldq2 : (int)a.ldq;
+    // Descriptors based at the chunk's first row with num_records = the chunk's bytes: a row past the chunk's end is out of
+    // range (returns 0) without a per-load guard.  Per thread the offsets inside a 32-row slab are constants (a column past
+    // Nout / Nin gets an out-of-range constant), the slab's first row goes into the instruction's scalar offset: no vector
+    // instruction per load in the K loop (VALU work shares the SIMD's issue with the MFMAs, gemm_split.h).
+    const char* pbase = reinterpret_cast<const char*>(a.P) + (PBF ? 2 : 4) * (r0 * a.ldp + i0);
+    const float* qbase = second ? a.Q2 + r0 * a.ldq2 + (j0 - a.nin_split) : a.Q + r0 * a.ldq + j0;
+    const long pbytes = (long)nrows * ldp * (PBF ? 2 : 4), qbytes = (long)nrows * ldq * 4;
+    const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pbase), 0, (int)(pbytes < 0x7FFFFFF0L ? pbytes : 0x7FFFFFF0L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qbase), 0, (int)(qbytes < 0x7FFFFFF0L ? qbytes : 0x7FFFFFF0L), 0x00020000);
+    int vp[4], vq[QSLOTS];
+    if (PBF) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int idx = tid + 256 * s, i = 8 * (idx & 15);
+            vp[s] = i0 + i < a.Nout ? 2 * ((idx >> 4) * ldp + i) : (int)Core::SRD_OOB;
+        }
+        vp[2] = vp[3] = 0;
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int slot = tid + 256 * s, i = 4 * (slot & 31);
+            vp[s] = i0 + i < a.Nout ? 4 * ((slot >> 5) * ldp + i) : (int)Core::SRD_OOB;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < QSLOTS; ++s) {
+        const int slot = tid + 256 * s, j = 4 * (slot % (BNW / 4));
+        vq[s] = j0 + j < a.Nin ? 4 * ((slot / (BNW / 4)) * ldq + j) : (int)Core::SRD_OOB;
+    }
+    const int sp_step = ldp * (PBF ? 2 : 4), sq_step = ldq * 4;      // bytes per row
 
     auto load = [&](int k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
+        const int sop = k0 * sp_step, soq = k0 * sq_step;
         if (PBF) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int idx = tid + 256 * s;
-                const int m = k0 + (idx >> 4), i = 8 * (idx & 15);
-                const bool ok = m < nrows && i0 + i < a.Nout;
-                const float4 raw = Core::srd_load(sp, ok ? 2u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
+                const float4 raw = buf_ld4(sp, vp[s], sop);
                 rp[2 * s] = widen_bf16x4(__float_as_uint(raw.x), __float_as_uint(raw.y));
                 rp[2 * s + 1] = widen_bf16x4(__float_as_uint(raw.z), __float_as_uint(raw.w));
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int slot = tid + 256 * s;
-                const int m = k0 + (slot >> 5), i = 4 * (slot & 31);
-                const bool ok = m < nrows && i0 + i < a.Nout;
-                rp[s] = Core::srd_load(sp, ok ? 4u * (unsigned)(m * ldp + i) : Core::SRD_OOB);
-            }
+            for (int s = 0; s < 4; ++s) rp[s] = buf_ld4(sp, vp[s], sop);
         }
 #pragma unroll
-        for (int s = 0; s < QSLOTS; ++s) {
-            const int slot = tid + 256 * s;
-            const int m = k0 + slot / (BNW / 4), j = 4 * (slot % (BNW / 4));
-            const bool ok = m < nrows && j0 + j < a.Nin;
-            rq[s] = Core::srd_load(sq, ok ? 4u * (unsigned)(m * ldq + j) : Core::SRD_OOB);
-        }
+        for (int s = 0; s < QSLOTS; ++s) rq[s] = buf_ld4(sq, vq[s], soq);
     };
     auto store = [&](int stage, const float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
         float* lp = lds + stage * (P_TILE + Q_TILE);
@@ -1244,8 +1259,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     auto colsum = [&](int stage) {
         if (a.colsum && j0 == 0 && tid < 128) {
             const float* lp = lds + stage * (P_TILE + Q_TILE);
-#pragma unroll 8
-            for (int k = 0; k < W_BK; ++k) csum += lp[k * W_LDP + tid];
+#pragma unroll
+            for (int k = 0; k < W_BK; k += 2) {      // two partial sums (even / odd rows): one packed add per two rows
+                const f32x2 v = {lp[k * W_LDP + tid], lp[(k + 1) * W_LDP + tid]};
+                csum2 += v;
+            }
         }
     };
 
@@ -1305,7 +1323,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
                 }
             }
         }
-    if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum;
+    if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum2[0] + csum2[1];
 }
 
 // ---- weight gradients on the bf16 matrix pipe (opt-in bf16x3 split, gemm_split.h) ---------------------------
