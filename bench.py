@@ -234,18 +234,25 @@ def stage_bytes(stage, M, C, F):
 
 # stage -> (substring of the kernel it launches) per GEMM mode, for matching PMC summaries
 def stage_kernel(stage, mode):
-    flat = {0: "gemm_flat_fast_kernel<regt::{epi}", 1: "gemm_flat_split_kernel<regt::{epi}", 2: "gemm_flat_split_kernel<regt::{epi}"}[mode]
-    epi = {"gemm_gates": "EpiGatesF", "dgrad_candidate": "EpiDgrad1F", "dgrad_gates": "EpiDgrad2F"}.get(stage)
+    """Substrings of the kernel names a stage may launch under GEMM mode ``mode`` (first match in a PMC summary wins): the
+    three-workgroup core gemm_flat_split_kernel<Epi, REGION, NP> with NP = 0 (fp32 planes) / 3 (bf16x3) / 1 (bf16), or the
+    8-column epilogue kernels when bf16 mode stores the activations as bf16."""
+    np_ = {0: 0, 1: 3, 2: 1}[mode]
+    epi = {"gemm_gates": "EpiGates", "dgrad_candidate": "EpiDgrad1", "dgrad_gates": "EpiDgrad2"}.get(stage)
     if epi:
-        return flat.format(epi=epi)
+        pats = [f"gemm_flat_split_kernel<regt::{epi}F, false, {np_}>"]
+        if mode == 2:
+            pats.insert(0, f"gemm_flat_split8_kernel<regt::{epi}8F, false>")
+        return pats
     if stage == "gemm_candidate":
-        return "gemm_cand_flat_kernel<regt::" + ("FastCore" if mode == 0 else "SplitCore")
+        return {0: ["gemm_cand_flat_kernel<regt::FastCore"], 1: ["gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
+                2: ["gemm_cand_flat8_kernel", "gemm_cand_flat_kernel<regt::SplitCore<false, 1>"]}[mode]
     if stage in ("wgrad_Uzr", "wgrad_Uh"):
-        return "wgrad_kernel<128>" if mode == 0 else "wgrad_split_kernel"
+        return ["wgrad_kernel<128"] if mode == 0 else ["wgrad_split_kernel"]
     if stage == "cell_bwd":
-        return "cell_bwd_kernel"
+        return ["cell_bwd8_kernel", "cell_bwd_kernel"] if mode == 2 else ["cell_bwd_kernel"]
     if stage == "spmm":
-        return "spmm_dual_panel_kernel"
+        return ["spmm_dual_panel_kernel"]
     return None
 
 
@@ -253,12 +260,14 @@ def pmc_traffic(workload, mode, stage):
     """(bytes per launch, source file) from the tracked PMC summary of this workload, or (None, None) when the file is absent
     or does not hold the kernel this run launches for ``stage`` (e.g. it was taken with an older kernel generation)."""
     path = PMC_SUMMARIES.get((workload, mode))
-    pat = stage_kernel(stage, mode)
-    if not path or not pat or not os.path.exists(os.path.join(ROOT, path)):
+    pats = stage_kernel(stage, mode)
+    if not path or not pats or not os.path.exists(os.path.join(ROOT, path)):
         return None, None
-    fetch = write = None
     with open(os.path.join(ROOT, path)) as f:
-        for line in f:
+        lines = f.readlines()
+    for pat in pats:
+        fetch = write = None
+        for line in lines:
             if pat not in line:
                 continue
             m = re.search(r"FETCH_SIZE=([0-9.e+]+)", line)
@@ -267,9 +276,9 @@ def pmc_traffic(workload, mode, stage):
             m = re.search(r"WRITE_SIZE=([0-9.e+]+)", line)
             if m and write is None:
                 write = float(m.group(1))
-    if fetch is None or write is None:
-        return None, None
-    return 2.0 * fetch * 1024 + write * 1024, path
+        if fetch is not None and write is not None:
+            return 2.0 * fetch * 1024 + write * 1024, path
+    return None, None
 
 
 def main():

@@ -1326,6 +1326,183 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     if (a.colsum && j0 == 0 && tid < 128 && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum2[0] + csum2[1];
 }
 
+// fp32 weight gradients on THREE workgroups per CU: 16-row half slabs (two LDS stages of 16 x 132 floats per operand,
+// 33,792 B), the half-step schedule of SplitCore::run_t (stage 0 / 1 = the halves of the current 32-row slab, the next slab
+// in registers, its halves stored while the other half is multiplied), <= 168 VGPRs.  The two-workgroup kernel above
+// reaches ~0.73 of the fp32 MFMA peak: one wave per SIMD and workgroup, every barrier and LDS round trip of a workgroup
+// idles its share of the matrix pipe unless another workgroup fills in.  Same tiling, chunking, arithmetic order inside a
+// chunk (k ascending, the same pairing of k to MFMA lanes) and output as wgrad_kernel<128, false>.
+__global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
+    constexpr int HK = 16, LDT = 128 + 4, OP_T = HK * LDT, STAGE = 2 * OP_T;      // floats
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_i = (a.Nout + 127) / 128, tiles_j = (a.Nin + 127) / 128;
+    const int tpc = tiles_i * tiles_j;
+    int tile, chunk;
+    {
+        const int nfull = (a.nchunks / 8) * 8;
+        const int b = blockIdx.x;
+        if (b < nfull * tpc) {
+            const int xcd = b & 7, li = b >> 3;
+            chunk = (li / tpc) * 8 + xcd;
+            tile = li % tpc;
+        } else {
+            const int r = b - nfull * tpc;
+            chunk = nfull + r / tpc;
+            tile = r % tpc;
+        }
+    }
+    const int i0 = (tile / tiles_j) * 128, j0 = (tile % tiles_j) * 128;
+    long r0, r1;
+    if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
+    else { r0 = (long)chunk * a.kchunk; r1 = r0 + a.kchunk < a.M ? r0 + a.kchunk : a.M; }
+    const int nrows = (int)(r1 - r0);
+    const int ldp = (int)a.ldp, ldq = (int)a.ldq;
+    const long pbytes = (long)nrows * ldp * 4, qbytes = (long)nrows * ldq * 4;
+    const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.P + r0 * a.ldp + i0), 0,
+                                                                       (int)(pbytes < 0x7FFFFFF0L ? pbytes : 0x7FFFFFF0L), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Q + r0 * a.ldq + j0), 0,
+                                                                       (int)(qbytes < 0x7FFFFFF0L ? qbytes : 0x7FFFFFF0L), 0x00020000);
+    // a half slab = 16 rows x 128 columns per operand = 512 float4: slots tid, tid + 256 -> row slot >> 5, column 4 (slot & 31)
+    int vp[2], vq[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int slot = tid + 256 * s, c4 = 4 * (slot & 31);
+        vp[s] = i0 + c4 < a.Nout ? 4 * ((slot >> 5) * ldp + c4) : (int)0x7FFFFFF8;
+        vq[s] = j0 + c4 < a.Nin ? 4 * ((slot >> 5) * ldq + c4) : (int)0x7FFFFFF8;
+    }
+    const int sp_step = HK * ldp * 4, sq_step = HK * ldq * 4;        // bytes per half slab
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x2 csum2 = {0.f, 0.f};
+    const bool do_colsum = a.colsum && j0 == 0 && tid < 128;
+
+    // registers of half h of a slab: rp[2 h + s], rq[2 h + s]
+    auto load_half = [&](int g, int h, float4 (&rp)[4], float4 (&rq)[4]) {       // g = half-slab index (rows 16 g ..); past the end: zeros
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            rp[2 * h + s] = buf_ld4(sp, vp[s], g * sp_step);
+            rq[2 * h + s] = buf_ld4(sq, vq[s], g * sq_step);
+        }
+    };
+    auto store_half = [&](int h, const float4 (&rp)[4], const float4 (&rq)[4]) {
+        float* lp = lds + h * STAGE;
+        float* lq = lp + OP_T;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int slot = tid + 256 * s;
+            float4 v = rq[2 * h + s];
+            if (a.q_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(lp + (slot >> 5) * LDT + 4 * (slot & 31)) = rp[2 * h + s];
+            *reinterpret_cast<float4*>(lq + (slot >> 5) * LDT + 4 * (slot & 31)) = v;
+        }
+    };
+    struct Frag { float a[2][8], b[2][8]; };       // [32-row block][k slot]: lane half lh holds k = 8 kk + 4 lh + j at slot 4 kk + j
+    auto read_frag = [&](int h) {
+        const float* lp = lds + h * STAGE;
+        const float* lq = lp + OP_T;
+        Frag f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kk * 8 + lh * 4 + j;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f.a[t][4 * kk + j] = lp[k * LDT + wr * 64 + t * 32 + lr];
+                    f.b[t][4 * kk + j] = lq[k * LDT + wc * 64 + t * 32 + lr];
+                }
+            }
+        return f;
+    };
+    auto mfma = [&](const Frag& f) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][q], f.b[ni][q], acc[mi][ni], 0, 0, 0);
+    };
+    auto colsum = [&](int h) {
+        if (do_colsum) {
+            const float* lp = lds + h * STAGE;
+#pragma unroll
+            for (int k = 0; k < HK; k += 2) {
+                const f32x2 v = {lp[k * LDT + tid], lp[(k + 1) * LDT + tid]};
+                csum2 += v;
+            }
+        }
+    };
+    // multiply half hc (in LDS) while half hs of the next slab is stored and the same half of the slab after next requested
+    auto fused = [&](int hs, int hc, int gnext, float4 (&rp)[4], float4 (&rq)[4]) {
+        __builtin_amdgcn_sched_barrier(0);
+        const Frag f = read_frag(hc);
+        store_half(hs, rp, rq);
+        mfma(f);
+        load_half(gnext, hs, rp, rq);
+        __builtin_amdgcn_sched_group_barrier(0x100, 32, 0);          // the fragment reads (ds_read_b32 / ds_read2)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);       // VALU | SALU
+            if (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // VMEM read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nslab = (nrows + 2 * HK - 1) / (2 * HK);
+    if (nslab > 0) {
+        float4 rp[4], rq[4];
+        load_half(0, 0, rp, rq);
+        load_half(1, 1, rp, rq);
+        store_half(0, rp, rq);
+        store_half(1, rp, rq);
+        load_half(2, 0, rp, rq);          // slab 1 (zeros past the chunk's end)
+        load_half(3, 1, rp, rq);
+        __syncthreads();
+        mfma(read_frag(0));
+        colsum(0);
+        for (int t = 0; t + 1 < nslab; ++t) {
+            __syncthreads();
+            fused(0, 1, 2 * t + 4, rp, rq);       // store half 2t+2 -> stage 0, multiply half 2t+1, request half 2t+4
+            colsum(1);
+            __syncthreads();
+            fused(1, 0, 2 * t + 5, rp, rq);
+            colsum(0);
+        }
+        __syncthreads();
+        mfma(read_frag(1));
+        colsum(1);
+    }
+    const long stride = (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0);
+    float* out = a.slab + (long)chunk * stride;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = i0 + wr * 64 + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (i < a.Nout) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int j = j0 + wc * 64 + ni * 32 + lr;
+                    if (j < a.Nin) out[(long)i * a.Nin + j] = acc[mi][ni][reg];
+                }
+            }
+        }
+    if (do_colsum && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum2[0] + csum2[1];
+}
+
+
 // ---- weight gradients on the bf16 matrix pipe (opt-in bf16x3 split, gemm_split.h) ---------------------------
 // Same tile (128 x 128), chunking, slab output and XCD mapping as wgrad_kernel<128>; the K loop follows SplitCore:
 // P and Q rows are split exactly into three bf16 planes while they are staged, two 16-row half slabs double-buffer
@@ -1716,6 +1893,9 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
             else if (a.p_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);
             else if (a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
             else hipLaunchKernelGGL((wgrad_split_kernel<1, false, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);
+        } else if (fast && !fp32_core_wide()) {
+            REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16), "wgrad: bf16-stored operands with the fp32 kernel");
+            hipLaunchKernelGGL(wgrad3_kernel, dim3((unsigned)blocks), dim3(256), 4 * 16 * 132 * 4, st, a);
         } else if (fast) {
             REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16), "wgrad: bf16-stored operands with the fp32 wide kernel");
             if (int rc = set_lds_once(&wgrad_kernel<128>, (int)lds, &attr_done)) return rc;
