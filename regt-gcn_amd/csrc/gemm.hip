@@ -1062,6 +1062,115 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat8_kernel(CandArgs a) {
     }
 }
 
+// Candidate stage on the three-workgroup core (fp32 planes NP = 0, bf16x3 NP = 3), fp32 storage.  Per 64-row half of the
+// tile: H~ = tanh(acc + ch) is stored, blended (p_t (Z h + (1 - Z) H~)) back into the half's LDS image, and the rows of
+// every node that intersects the half are summed and added to OH with one atomic per element -- a node of T <= 64 rows
+// meets at most two halves (tile boundaries are half boundaries), so every OH element is 0 + a + b: order-independent.
+// The row -> (node, period) map costs one integer division per tile ROW (row table in LDS, written before the K loop),
+// not one 64-bit modulo per row slot of every thread; arrays are addressed through buffer descriptors (one per array
+// and tile); a full tile runs without a single branch (see the functor notes at the top of this file).
+struct CandRowEnt { int nt; float p; };        // nt = (node - first node of the tile) << 8 | period
+template <int NP, bool FULL>
+__device__ __forceinline__ void cand_epilogue(const CandArgs& a, const SplitCore<false, NP>& core, f32x16 (&acc)[2][2], float* lds,
+                                              const CandRowEnt* rowtab, long m0, int n0, int nvalid, int node0, int t0) {
+    const int tid = threadIdx.x, rr = tid >> 5, c4 = 4 * (tid & 31);
+    const int C = a.C;
+    const bool col_ok = FULL || n0 + c4 < C;
+    const __amdgpu_buffer_rsrc_t szr = buf_srd(a.ZR + m0 * (2L * C) + n0), sh = buf_srd(a.h + m0 * C + n0), sht = buf_srd(a.Ht + m0 * C + n0);
+    const int vc = (rr * C + c4) * 4, vzr = (rr * 2 * C + c4) * 4, sc = 8 * C * 4, szs = 2 * sc;
+    const float4 b = col_ok ? ld4(a.bias + n0 + c4) : make_float4(0, 0, 0, 0);
+    constexpr int RR = 4, NR = 16 / RR;
+    float4 Z[2][RR], hv[2][RR];
+    auto request = [&](int k, float4 (&Zd)[RR], float4 (&hd)[RR]) {
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int i = RR * k + j;
+            if (FULL || (rr + 8 * i < nvalid && col_ok)) {
+                Zd[j] = buf_ld4(szr, vzr, i * szs);
+                hd[j] = buf_ld4(sh, vc, i * sc);
+            }
+        }
+    };
+    request(0, Z[0], hv[0]);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int half = k / (NR / 2);
+        if (k % (NR / 2) == 0) core.stage_half(half, acc);
+        if (k + 1 < NR) request(k + 1, Z[(k + 1) & 1], hv[(k + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int i = RR * k + j, rl = rr + 8 * (i & 7);          // row rr + 8 i of the tile = row rl of its half
+            if (FULL || (rr + 8 * i < nvalid && col_ok)) {
+                float* img = lds + rl * G_LDS_KROW + c4;
+                const float4 v = *reinterpret_cast<const float4*>(img);
+                const float pt = rowtab[rr + 8 * i].p;
+#define F_(q) fast_tanh(v.q + b.q)
+                const float4 ht = REGT_V4(F_);
+#undef F_
+                buf_st4(sht, vc + i * sc, 0, ht);
+                const float4 Zv = Z[k & 1][j], hh = hv[k & 1][j];
+#define F_(q) (pt * (Zv.q * hh.q + (1.0f - Zv.q) * ht.q))
+                *reinterpret_cast<float4*>(img) = REGT_V4(F_);
+#undef F_
+            }
+        }
+        if (k % (NR / 2) == NR / 2 - 1) {
+            // the half is blended: segmented sums over the nodes that intersect it
+            __syncthreads();
+            const int r_lo = 64 * half, r_hi = (FULL ? 64 * half + 63 : (nvalid - 1 < 64 * half + 63 ? nvalid - 1 : 64 * half + 63));
+            if (FULL || r_hi >= r_lo) {
+                const int n_first = rowtab[r_lo].nt >> 8, n_last = rowtab[r_hi].nt >> 8;
+                for (int nd = n_first + rr; nd <= n_last; nd += 8) {
+                    int lo = nd * a.T - t0, hi = lo + a.T - 1;               // the node's rows in tile coordinates
+                    lo = lo < r_lo ? r_lo : lo;
+                    hi = hi > r_hi ? r_hi : hi;
+                    float4 s4 = make_float4(0, 0, 0, 0);
+                    for (int r = lo; r <= hi; ++r) {
+                        const float4 v = *reinterpret_cast<const float4*>(lds + (r - r_lo) * G_LDS_KROW + c4);
+                        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+                    }
+                    if (col_ok) {
+                        float* o = a.OH + (long)(node0 + nd) * C + n0 + c4;
+                        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+                    }
+                }
+            }
+        }
+    }
+}
+template <int NP>
+__global__ __launch_bounds__(256, 3) void gemm_cand_split_kernel(CandArgs a, int uniform) {
+    using Core = SplitCore<false, NP>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const long M = (long)a.num_nodes * a.T;
+    const int tiles_n = (a.C + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    const RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    Core core(a.S, rm, n0, a.C, lds, true);
+    CandRowEnt* rowtab = reinterpret_cast<CandRowEnt*>(core.rowtab());
+    // first node / period of the tile: ONE 32-bit division per thread (M < 2^31, host-checked); row r then needs a small
+    // quotient only ((t0 + r) / T by float reciprocal, exact below 2^16: the +0.5 keeps it off the integer boundaries)
+    const int node0 = (int)((unsigned)m0 / (unsigned)a.T), t0 = (int)m0 - node0 * a.T;
+    if (threadIdx.x < GBM) {
+        const int x = t0 + (threadIdx.x < rm.nvalid ? threadIdx.x : 0), q = (int)(((float)x + 0.5f) * (1.0f / (float)a.T));
+        rowtab[threadIdx.x] = CandRowEnt{(q << 8) | (x - q * a.T), a.probs[x - q * a.T]};
+    }
+    if (!uniform) core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (uniform) core.run_uniform(acc, false);
+    else core.run(acc, false);
+    if (rm.nvalid == GBM && n0 + GBN <= a.C) cand_epilogue<NP, true>(a, core, acc, lds, rowtab, m0, n0, GBM, node0, t0);
+    else cand_epilogue<NP, false>(a, core, acc, lds, rowtab, m0, n0, rm.nvalid, node0, t0);
+}
+
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
@@ -1077,7 +1186,13 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
         REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
-        if (gemm_mode() == 1)
+        // three-workgroup kernels (fp32 storage): 64-row halves need T <= 64 (a node meets at most two halves)
+        const bool three = !a.act_bf16 && !fp32_core_wide() && gemm_mode() != 2 && (gemm_mode() == 1 || ftiles >= SMALL_TILE_LIMIT) && M < (1L << 31);
+        if (three && gemm_mode() == 0)
+            hipLaunchKernelGGL((gemm_cand_split_kernel<0>), dim3((unsigned)ftiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, a, uniform_ok(a.S, M));
+        else if (three)
+            hipLaunchKernelGGL((gemm_cand_split_kernel<3>), dim3((unsigned)ftiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, a, uniform_ok(a.S, M));
+        else if (gemm_mode() == 1)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 3>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
         else if (gemm_mode() == 2 && a.act_bf16) {
             static bool attr_done8 = false;
