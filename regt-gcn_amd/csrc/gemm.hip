@@ -417,6 +417,17 @@ __device__ __forceinline__ void st8(void* base, long elem, const F8& v, int bf) 
     }
 }
 #define REGT_F8(expr) F8{make_float4(expr(lo.x), expr(lo.y), expr(lo.z), expr(lo.w)), make_float4(expr(hi.x), expr(hi.y), expr(hi.z), expr(hi.w))}
+// 16 bytes = 8 bf16 through a buffer descriptor (straight-line variants; stores keep soffset = 0, see the note on top)
+__device__ __forceinline__ u32x4_t buf_ld16(__amdgpu_buffer_rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
+__device__ __forceinline__ F8 widen8(u32x4_t raw) { return F8{widen_bf16x4(raw.x, raw.y), widen_bf16x4(raw.z, raw.w)}; }
+__device__ __forceinline__ void buf_st8_bf16(__amdgpu_buffer_rsrc_t r, int voff, const F8& v) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t a = {v.lo.x, v.lo.y}, b = {v.lo.z, v.lo.w}, c = {v.hi.x, v.hi.y}, d = {v.hi.z, v.hi.w};
+    const u32x4_t raw = {__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_t)),
+                         __builtin_bit_cast(unsigned, __builtin_convertvector(c, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(d, bf16x2_t))};
+    __builtin_amdgcn_raw_buffer_store_b128(raw, r, voff, 0, 0);
+}
 
 struct EpiBiasAct8F {
     typedef F8 Vec;
@@ -437,6 +448,24 @@ struct EpiBiasAct8F {
     __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux& ca, const Aux&) const {
 #define F_(k) act(v.k + ca.b.k)
         st8(e.out, m * e.ldo + c, REGT_F8(F_), e.out_bf16);
+#undef F_
+    }
+    // straight-line variants (bf16 output): 0 = none / leaky relu / relu, 1 = sigmoid, 2 = tanh
+    static constexpr int NVAR = 3;
+    static constexpr bool HAS_ROWTAB = false;
+    typedef ColAux Col;
+    struct VAux {};
+    struct Tile { __amdgpu_buffer_rsrc_t out; int v, s; };
+    __device__ __forceinline__ int variant(int) const { return !e.out_bf16 ? -1 : (e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0)); }
+    template <int V> __device__ __forceinline__ Col vcol(int c) const { return col(c); }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        return Tile{buf_srd(reinterpret_cast<const char*>(e.out) + 2 * (g.m0 * e.ldo + g.n0)), (g.rr * (int)e.ldo + g.c) * 2, g.step * (int)e.ldo * 2};
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile&, int) const { return VAux{}; }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, const F8& v, const Col& ca, const VAux&) const {
+        const float ns = e.act == ACT_NONE ? 1.0f : (e.act == ACT_LRELU ? e.slope : 0.0f);
+#define F_(k) (V == 1 ? fast_sigmoid(v.k + ca.b.k) : V == 2 ? fast_tanh(v.k + ca.b.k) : ((v.k + ca.b.k) > 0.f ? (v.k + ca.b.k) : (v.k + ca.b.k) * ns))
+        buf_st8_bf16(t.out, t.v + i * t.s, REGT_F8(F_));
 #undef F_
     }
 };
@@ -460,6 +489,45 @@ struct EpiGates8F {
         if (c >= e.C) {
 #define F_(k) (a.h.k * g.k)
             st8(e.q, m * e.C + c - e.C, REGT_F8(F_), e.q_bf16);
+#undef F_
+        }
+    }
+    // straight-line variants (h, [Z|R] and q all stored as bf16): bit 0 = the tile holds r columns
+    static constexpr int NVAR = 2;
+    static constexpr bool HAS_ROWTAB = false;
+    typedef ColAux Col;
+    struct VAux { u32x4_t h; };
+    struct Tile { __amdgpu_buffer_rsrc_t zr, h, q; int vzr, vh, szr, sh; };
+    __device__ __forceinline__ int variant(int n0) const { return (e.C % GBN || !e.h_bf16 || !e.zr_bf16 || !e.q_bf16) ? -1 : (n0 >= e.C ? 1 : 0); }
+    template <int V> __device__ __forceinline__ Col vcol(int c) const { return col(c); }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.zr = buf_srd(reinterpret_cast<const char*>(e.ZR) + 2 * (g.m0 * (2L * e.C) + g.n0));
+        t.vzr = (g.rr * 2 * e.C + g.c) * 2;
+        t.szr = g.step * 2 * e.C * 2;
+        if (V & 1) {
+            const long o = g.m0 * e.C + g.n0 - e.C;
+            t.h = buf_srd(reinterpret_cast<const char*>(e.h) + 2 * o);
+            t.q = buf_srd(reinterpret_cast<const char*>(e.q) + 2 * o);
+            t.vh = (g.rr * e.C + g.c) * 2;
+            t.sh = g.step * e.C * 2;
+        }
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
+        VAux a;
+        if (V & 1) a.h = buf_ld16(t.h, t.vh, i * t.sh);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, const F8& v, const Col& ca, const VAux& a) const {
+#define F_(k) fast_sigmoid(v.k + ca.b.k)
+        const F8 g = REGT_F8(F_);
+#undef F_
+        buf_st8_bf16(t.zr, t.vzr + i * t.szr, g);
+        if (V & 1) {
+            const F8 h = widen8(a.h);
+#define F_(k) (h.k * g.k)
+            buf_st8_bf16(t.q, t.vh + i * t.sh, REGT_F8(F_));
 #undef F_
         }
     }
@@ -489,6 +557,54 @@ struct EpiDgrad18F {
         st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
 #undef F_
     }
+    // straight-line variant (h, [Z|R], dzr, dh all stored as bf16); row -> (node, period) through the LDS row table
+    static constexpr int NVAR = 1;
+    static constexpr bool HAS_ROWTAB = true;
+    typedef ColAux Col;
+    struct VAux { u32x4_t h, Z, R; float4 d0, d1; float p; };
+    struct Tile { __amdgpu_buffer_rsrc_t h, zr, d, dzr, dh; int vc, vzr, sc, szr, vd, rstep; const EpiRowEnt* rt; };
+    __device__ __forceinline__ int variant(int) const { return (e.h_bf16 && e.zr_bf16 && e.dzr_bf16 && e.dh_bf16) ? 0 : -1; }
+    __device__ __forceinline__ EpiRowEnt vrow(long m) const {
+        const long node = m / e.T;
+        return EpiRowEnt{(int)(node * e.C * 4), e.probs[(int)(m - node * e.T)]};
+    }
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.h = buf_srd(reinterpret_cast<const char*>(e.h) + 2 * (g.m0 * e.C + g.n0));
+        t.dh = buf_srd(reinterpret_cast<const char*>(e.dh) + 2 * (g.m0 * e.C + g.n0));
+        t.zr = buf_srd(reinterpret_cast<const char*>(e.ZR) + 2 * (g.m0 * (2L * e.C) + g.n0));
+        t.dzr = buf_srd(reinterpret_cast<const char*>(e.dzr) + 2 * (g.m0 * (2L * e.C) + e.C + g.n0));
+        t.d = buf_srd(e.dOH + g.n0);
+        t.vc = (g.rr * e.C + g.c) * 2;
+        t.sc = g.step * e.C * 2;
+        t.vzr = (g.rr * 2 * e.C + g.c) * 2;
+        t.szr = 2 * t.sc;
+        t.vd = g.c * 4;
+        t.rstep = g.step;
+        t.rt = g.rowtab + g.rr;
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
+        const EpiRowEnt re = t.rt[i * t.rstep];
+        VAux a;
+        a.p = re.p;
+        a.h = buf_ld16(t.h, t.vc, i * t.sc);
+        a.Z = buf_ld16(t.zr, t.vzr, i * t.szr);
+        a.R = buf_ld16(t.zr, t.vzr, i * t.szr + e.C * 2);
+        a.d0 = buf_ld4(t.d, t.vd + re.off, 0);
+        a.d1 = buf_ld4(t.d, t.vd + re.off, 16);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, const F8& v, const Col&, const VAux& a) const {
+        const F8 h = widen8(a.h), Z = widen8(a.Z), R = widen8(a.R), d = F8{a.d0, a.d1};
+#define F_(k) (v.k * h.k * (R.k * (1.0f - R.k)))
+        buf_st8_bf16(t.dzr, t.vzr + i * t.szr, REGT_F8(F_));
+#undef F_
+#define F_(k) (v.k * R.k + a.p * d.k * Z.k)
+        buf_st8_bf16(t.dh, t.vc + i * t.sc, REGT_F8(F_));
+#undef F_
+    }
 };
 struct EpiDgrad28F {
     typedef F8 Vec;
@@ -507,6 +623,36 @@ struct EpiDgrad28F {
     __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux&, const Aux& a) const {
 #define F_(k) ((a.d.k + v.k) * (a.h.k > 0.f ? 1.0f : e.slope))
         st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
+#undef F_
+    }
+    // straight-line variants (dh and h stored as bf16): bit 0 = leaky-relu derivative (reads h)
+    static constexpr int NVAR = 2;
+    static constexpr bool HAS_ROWTAB = false;
+    typedef ColAux Col;
+    struct VAux { u32x4_t d, h; };
+    struct Tile { __amdgpu_buffer_rsrc_t dh, h; int v, s; };
+    __device__ __forceinline__ int variant(int) const { return (e.dh_bf16 && e.h_bf16) ? (e.act == ACT_LRELU ? 1 : 0) : -1; }
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.dh = buf_srd(reinterpret_cast<const char*>(e.dh) + 2 * (g.m0 * e.C + g.n0));
+        if (V & 1) t.h = buf_srd(reinterpret_cast<const char*>(e.h) + 2 * (g.m0 * e.C + g.n0));
+        t.v = (g.rr * e.C + g.c) * 2;
+        t.s = g.step * e.C * 2;
+        return t;
+    }
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
+        VAux a;
+        a.d = buf_ld16(t.dh, t.v, i * t.s);
+        if (V & 1) a.h = buf_ld16(t.h, t.v, i * t.s);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, const F8& v, const Col&, const VAux& a) const {
+        const F8 d = widen8(a.d);
+        F8 h = d;
+        if (V & 1) h = widen8(a.h);
+#define F_(k) ((d.k + v.k) * ((V & 1) ? (h.k > 0.f ? 1.0f : e.slope) : 1.0f))
+        buf_st8_bf16(t.dh, t.v + i * t.s, REGT_F8(F_));
 #undef F_
     }
 };
@@ -597,7 +743,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
 
 // bf16-operand core + 8-column epilogue (bf16 storage of the activations): same K loop as gemm_flat_split_kernel<.., 1>
 template <class EpiF8, bool REGION>
-__global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, long M, int N, EpiF8 epi) {
+__global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, long M, int N, EpiF8 epi, int uniform) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -605,7 +751,9 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, lo
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
     SplitCore<REGION, 1> core(S, rm, n0, N, lds, true);
-    core.plan();
+    core.fill_rowtab(epi);
+    const bool uni = !REGION && uniform != 0;
+    if (!uni) core.plan();
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -614,7 +762,8 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, lo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     WG_TRACE_T(t_a);
-    core.run(acc, false);
+    if (uni) core.run_uniform(acc, false);
+    else core.run(acc, false);
     WG_TRACE_T(t_b);
     core.for_each_vec8_halves(acc, epi);
     WG_TRACE_END(N, t_a, t_b);
@@ -757,7 +906,7 @@ static int launch_split8(const GemmSegs& S, long M, int N, EpiF8 f, hipStream_t 
     REGT_CHECK_ARG(gemm_mode() == 2 && N % 8 == 0, "gemm: bf16-stored activations need REGT_GEMM_MODE=bf16 and N %% 8 == 0");
     const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-    hipLaunchKernelGGL((gemm_flat_split8_kernel<EpiF8, REGION>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f);
+    hipLaunchKernelGGL((gemm_flat_split8_kernel<EpiF8, REGION>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, uniform_ok(S, M));
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

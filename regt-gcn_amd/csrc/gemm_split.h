@@ -530,10 +530,42 @@ struct SplitCore : FastCore<true, REGION> {
 
     // 8-column-per-thread form of the half-tile epilogue (functors of gemm.hip's "8F" family): thread = (row tid >> 4 (+16 i),
     // columns 8 (tid & 15) .. +7) -- 16 bytes per access of a bf16 array, two float4 of an fp32 one.
+    // straight-line body of the 8-column form (full tile + functor variant): row slots i = 0 .. 7, row (tid >> 4) + 16 i
+    template <class F, int V>
+    __device__ __forceinline__ void vec8_body_halves(f32x16 (&acc)[2][2], const F& f) const {
+        constexpr int AB = (int)sizeof(typename F::VAux);
+        constexpr int RR = AB * 4 <= 96 ? 4 : (AB * 2 <= 96 ? 2 : 1), RPH = 4 / RR, NR = 2 * RPH;
+        const EpiGeom geo{rm.base, n0, tid >> 4, 8 * (tid & 15), 16, Base::rowtab()};
+        const typename F::Tile tl = f.template vtile<V>(geo);
+        const typename F::Col col = f.template vcol<V>(n0 + 8 * (tid & 15));
+        typename F::VAux aux[2][RR];
+#pragma unroll
+        for (int j = 0; j < RR; ++j) aux[0][j] = f.template vload<V>(tl, j);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            if (k % RPH == 0) stage_half(k / RPH, acc);
+            if (k + 1 < NR) {
+#pragma unroll
+                for (int j = 0; j < RR; ++j) aux[(k + 1) & 1][j] = f.template vload<V>(tl, RR * (k + 1) + j);
+            }
+#pragma unroll
+            for (int j = 0; j < RR; ++j) {
+                const int i = RR * k + j;
+                const float4* img = reinterpret_cast<const float4*>(lds + ((tid >> 4) + 16 * (i & 3)) * G_LDS_KROW + 8 * (tid & 15));
+                f.template vapply<V>(tl, i, typename F::Vec{img[0], img[1]}, col, aux[k & 1][j]);
+            }
+        }
+        __syncthreads();
+    }
     template <class F>
     __device__ __forceinline__ void for_each_vec8_halves(f32x16 (&acc)[2][2], const F& f) const {
         constexpr int RR = F::ROUND_ROWS;          // of the thread's 4 rows per half
         static_assert(RR == 1 || RR == 2 || RR == 4, "rows per epilogue round");
+        const int v = Base::tile_variant(f);
+        if (v >= 0) {
+            Base::template dispatch_variant<F, 0>(v, [&](auto tag) { vec8_body_halves<F, decltype(tag)::value>(acc, f); });
+            return;
+        }
         const int lr = lane & 31, lh = lane >> 5;
         const int c = n0 + 8 * (tid & 15);
         const bool live = c < N;
