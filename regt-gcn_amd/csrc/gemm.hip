@@ -1320,6 +1320,113 @@ __global__ __launch_bounds__(256, 3) void gemm_cand_split_kernel(CandArgs a, int
     else cand_epilogue<NP, false>(a, core, acc, lds, rowtab, m0, n0, rm.nvalid, node0, t0);
 }
 
+// The same with Z, h and H~ stored as bf16 (REGT_GEMM_MODE=bf16, bf16-operand core NP = 1): 8 columns per thread (16-byte
+// accesses of the bf16 arrays), row slots i = 0 .. 7: row (tid >> 4) + 16 i.
+template <bool FULL>
+__device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCore<false, 1>& core, f32x16 (&acc)[2][2], float* lds,
+                                               const CandRowEnt* rowtab, long m0, int n0, int nvalid, int node0, int t0) {
+    const int tid = threadIdx.x, rr = tid >> 4, c8 = 8 * (tid & 15);
+    const int C = a.C;
+    const bool col_ok = FULL || n0 + c8 < C;
+    const __amdgpu_buffer_rsrc_t szr = buf_srd(reinterpret_cast<const char*>(a.ZR) + 2 * (m0 * (2L * C) + n0)),
+                                 sh = buf_srd(reinterpret_cast<const char*>(a.h) + 2 * (m0 * C + n0)),
+                                 sht = buf_srd(reinterpret_cast<const char*>(a.Ht) + 2 * (m0 * C + n0));
+    const int vc = (rr * C + c8) * 2, vzr = (rr * 2 * C + c8) * 2, sc = 16 * C * 2, szs = 2 * sc;
+    F8 b{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (col_ok) b = ld8(a.bias, n0 + c8, 0);
+    constexpr int RR = 2, NR = 8 / RR;
+    u32x4_t Z[2][RR], hv[2][RR];
+    auto request = [&](int k, u32x4_t (&Zd)[RR], u32x4_t (&hd)[RR]) {
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int i = RR * k + j;
+            if (FULL || (rr + 16 * i < nvalid && col_ok)) {
+                Zd[j] = buf_ld16(szr, vzr, i * szs);
+                hd[j] = buf_ld16(sh, vc, i * sc);
+            }
+        }
+    };
+    request(0, Z[0], hv[0]);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int half = k / (NR / 2);
+        if (k % (NR / 2) == 0) core.stage_half(half, acc);
+        if (k + 1 < NR) request(k + 1, Z[(k + 1) & 1], hv[(k + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < RR; ++j) {
+            const int i = RR * k + j, rl = rr + 16 * (i & 3);
+            if (FULL || (rr + 16 * i < nvalid && col_ok)) {
+                float4* img = reinterpret_cast<float4*>(lds + rl * G_LDS_KROW + c8);
+                const F8 v{img[0], img[1]};
+                const float pt = rowtab[rr + 16 * i].p;
+#define F_(q) fast_tanh(v.q + b.q)
+                const F8 ht = REGT_F8(F_);
+#undef F_
+                buf_st8_bf16(sht, vc + i * sc, ht);
+                const F8 Zv = widen8(Z[k & 1][j]), hh = widen8(hv[k & 1][j]);
+#define F_(q) (pt * (Zv.q * hh.q + (1.0f - Zv.q) * ht.q))
+                const F8 o = REGT_F8(F_);
+#undef F_
+                img[0] = o.lo;
+                img[1] = o.hi;
+            }
+        }
+        if (k % (NR / 2) == NR / 2 - 1) {
+            __syncthreads();
+            const int r_lo = 64 * half, r_hi = (FULL ? 64 * half + 63 : (nvalid - 1 < 64 * half + 63 ? nvalid - 1 : 64 * half + 63));
+            if (FULL || r_hi >= r_lo) {
+                const int n_first = rowtab[r_lo].nt >> 8, n_last = rowtab[r_hi].nt >> 8;
+                for (int nd = n_first + rr; nd <= n_last; nd += 16) {
+                    int lo = nd * a.T - t0, hi = lo + a.T - 1;
+                    lo = lo < r_lo ? r_lo : lo;
+                    hi = hi > r_hi ? r_hi : hi;
+                    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+                    for (int r = lo; r <= hi; ++r) {
+                        const float4* p = reinterpret_cast<const float4*>(lds + (r - r_lo) * G_LDS_KROW + c8);
+                        const float4 u = p[0], w = p[1];
+                        s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+                        s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
+                    }
+                    if (col_ok) {
+                        float* o = a.OH + (long)(node0 + nd) * C + n0 + c8;
+                        atomicAdd(o + 0, s0.x); atomicAdd(o + 1, s0.y); atomicAdd(o + 2, s0.z); atomicAdd(o + 3, s0.w);
+                        atomicAdd(o + 4, s1.x); atomicAdd(o + 5, s1.y); atomicAdd(o + 6, s1.z); atomicAdd(o + 7, s1.w);
+                    }
+                }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256, 3) void gemm_cand_split8_kernel(CandArgs a, int uniform) {
+    using Core = SplitCore<false, 1>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const long M = (long)a.num_nodes * a.T;
+    const int tiles_n = (a.C + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    const RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    Core core(a.S, rm, n0, a.C, lds, true);
+    CandRowEnt* rowtab = reinterpret_cast<CandRowEnt*>(core.rowtab());
+    const int node0 = (int)((unsigned)m0 / (unsigned)a.T), t0 = (int)m0 - node0 * a.T;
+    if (threadIdx.x < GBM) {
+        const int x = t0 + (threadIdx.x < rm.nvalid ? threadIdx.x : 0), q = (int)(((float)x + 0.5f) * (1.0f / (float)a.T));
+        rowtab[threadIdx.x] = CandRowEnt{(q << 8) | (x - q * a.T), a.probs[x - q * a.T]};
+    }
+    if (!uniform) core.plan();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (uniform) core.run_uniform(acc, false);
+    else core.run(acc, false);
+    if (rm.nvalid == GBM && n0 + GBN <= a.C) cand8_epilogue<true>(a, core, acc, lds, rowtab, m0, n0, GBM, node0, t0);
+    else cand8_epilogue<false>(a, core, acc, lds, rowtab, m0, n0, rm.nvalid, node0, t0);
+}
+
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.num_nodes > 0 && a.T > 0 && a.C > 0, "candidate gemm: empty problem");
     long tiles = (long)cdiv(a.num_nodes, GBM) * cdiv(a.C, GBN);
@@ -1343,6 +1450,8 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_cand_split_kernel<3>), dim3((unsigned)ftiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, a, uniform_ok(a.S, M));
         else if (gemm_mode() == 1)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 3>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
+        else if (gemm_mode() == 2 && a.act_bf16 && a.C % 8 == 0 && M < (1L << 31) && !fp32_core_wide())
+            hipLaunchKernelGGL(gemm_cand_split8_kernel, dim3((unsigned)ftiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, a, uniform_ok(a.S, M));
         else if (gemm_mode() == 2 && a.act_bf16) {
             static bool attr_done8 = false;
             REGT_CHECK_ARG(a.C % 8 == 0, "candidate gemm: bf16 storage needs C %% 8 == 0");
