@@ -217,19 +217,22 @@ def stage_flops(stage, M, C, F):
     }.get(stage)
 
 
-def stage_bytes(stage, M, C, F):
-    """Algorithmic HBM bytes of one launch: every activation operand read once, every result written once (fp32 storage);
-    weights and per-node vectors are negligible.  DESIGN.md section 5 states the same figures."""
+def stage_bytes(stage, M, C, F, mode=0):
+    """Algorithmic HBM bytes of one launch: every activation operand read once, every result written once; weights and
+    per-node vectors are negligible.  fp32 storage (4 B) except under GEMM mode 2 (bf16), where the M x C activations
+    (h, [Z|R], q, H~, dh, dhp, dzp|drp) are stored as bf16 (2 B); x, A_hat x, L~ x stay fp32.  DESIGN.md section 5."""
+    a = 2.0 if mode == 2 else 4.0       # bytes per element of an M x C activation
     per_row = {
-        "gemm_gates": C + F + 2 * C + C,          # read h, A_hat x; write [Z|R], q
-        "gemm_candidate": C + F + C + C + C,      # read q, A_hat x, Z, h; write H~
-        "gemm_regional": 2 * F + C,               # read x, L~ x; write h
-        "cell_bwd": 3 * C + 2 * C,                # read Z, h, H~; write dhp, dzp
-        "dgrad_candidate": C + C + 2 * C + 2 * C,  # read dhp, h, Z, R; write drp, dh
-        "dgrad_gates": 2 * C + C + C + C,         # read dzp|drp, dh, h; write ds
-        "wgrad_Uzr": 3 * C, "wgrad_Uh": 2 * C, "wgrad_Gzr": 2 * C + F, "wgrad_Gh": C + F, "wgrad_A0_Ar": C + 2 * F,
+        "gemm_gates": a * C + 4.0 * F + a * 2 * C + a * C,          # read h, A_hat x; write [Z|R], q
+        "gemm_candidate": a * C + 4.0 * F + a * C + a * C + a * C,  # read q, A_hat x, Z, h; write H~
+        "gemm_regional": 4.0 * 2 * F + a * C,                       # read x, L~ x; write h
+        "cell_bwd": a * 3 * C + a * 2 * C,                          # read Z, h, H~; write dhp, dzp
+        "dgrad_candidate": a * (C + C + 2 * C) + a * 2 * C,         # read dhp, h, Z, R; write drp, dh
+        "dgrad_gates": a * (2 * C + C + C) + a * C,                 # read dzp|drp, dh, h; write ds
+        "wgrad_Uzr": a * 3 * C, "wgrad_Uh": a * 2 * C, "wgrad_Gzr": a * 2 * C + 4.0 * F, "wgrad_Gh": a * C + 4.0 * F,
+        "wgrad_A0_Ar": a * C + 4.0 * 2 * F,
     }.get(stage)
-    return None if per_row is None else 4.0 * M * per_row
+    return None if per_row is None else M * per_row
 
 
 # stage -> (substring of the kernel it launches) per GEMM mode, for matching PMC summaries
@@ -496,14 +499,14 @@ def main():
                 e = {"launches": c, "avg_ms": ms / c}
                 if stage_flops(k, M, C, F):
                     e["tflops"] = stage_flops(k, M, C, F) / (ms / c * 1e-3) / 1e12
-                if stage_bytes(k, M, C, F):
-                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F) / (ms / c * 1e-3) / 1e9
+                if stage_bytes(k, M, C, F, mode):
+                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F, mode) / (ms / c * 1e-3) / 1e9
                 per[k] = e
             mfma = [(ms, k) for k, (c, ms) in stages.items() if stage_flops(k, M, C, F)]
             tot_ms, dom = max(mfma)
             cnt = stages[dom][0]
             avg_s = tot_ms / cnt * 1e-3
-            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F)
+            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F, mode)
             tflops, gbs = fl / avg_s / 1e12, by / avg_s / 1e9
             traffic, src = pmc_traffic(args.workload, mode, dom)
             mfma_peak = PEAK_FP32_MATRIX_TFLOPS if mode == 0 else PEAK_BF16_MATRIX_TFLOPS
@@ -516,8 +519,8 @@ def main():
             if mode == 1:
                 r_mfma["note"] = ("fp32-equivalent FLOP/s of the exact 3-way split against the bf16 dense peak: the matrix pipe "
                                   "executes 6 bf16 products per fp32 product, so the ceiling of this arithmetic is peak / 6")
-            # the bound that binds: the larger fraction of its own roof (fp32 MFMA GEMMs sit at the matrix pipe, the bf16 ones
-            # at HBM -- their operands are still stored in fp32)
+            # the bound that binds: the larger fraction of its own roof (fp32 MFMA GEMMs sit at the matrix pipe; the bf16 ones
+            # at HBM, with the M x C activations stored as bf16 -- stage_bytes counts 2 bytes for them)
             if r_mfma["frac"] >= r_hbm["frac"]:
                 out["roofline"], out["roofline_other_bound"] = r_mfma, r_hbm
             else:
