@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
     SplitCore<REGION, NP> core(S, rm, n0, N, lds, true);
     WG_MARK(7);
     core.fill_rowtab(epi);
-    const bool uni = !REGION && uniform != 0;      // scalar slab descriptors (host: uniform_ok): no iteration table
+    const bool uni = uniform != 0;                 // scalar slab descriptors (host: uniform_ok): no iteration table
     if (!uni) core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, lo
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
     SplitCore<REGION, 1> core(S, rm, n0, N, lds, true);
     core.fill_rowtab(epi);
-    const bool uni = !REGION && uniform != 0;
+    const bool uni = uniform != 0;
     if (!uni) core.plan();
     f32x16 acc[2][2];
 #pragma unroll
@@ -807,15 +807,15 @@ bool fp32_core_wide() {
     return wide == 1;
 }
 
-// the K loop may keep its slab descriptors in scalar registers (SplitCore::run_u): no region-masked segment, every K a
-// multiple of the 32-k slab, byte offsets of a tile's rows within 31 bits.  REGT_GEMM_DESC=table forces the LDS table.
+// the K loop may keep its slab descriptors in scalar registers (SplitCore::run_u): every K a multiple of the 32-k slab, byte offsets of a tile's rows within 31 bits.  REGT_GEMM_DESC=table forces the LDS table.
 static int uniform_ok(const GemmSegs& S, long M) {
     static int force_table = -1;
     if (force_table < 0) { const char* e = getenv("REGT_GEMM_DESC"); force_table = e && !strcmp(e, "table") ? 1 : 0; }
     if (force_table) return 0;
     for (int s = 0; s < S.nseg; ++s) {
         const GemmSeg& g = S.seg[s];
-        if ((g.flags & SEG_REGION) || g.K % GBK != 0 || g.K <= 0) return 0;
+        if (g.K % GBK != 0 || g.K <= 0) return 0;
+        if ((g.flags & SEG_REGION) && (g.flags & SEG_A_BF16)) return 0;       // bf16 rows are never region-masked
         if (g.lda * 4 * (GBM + 1) >= (1L << 31) || g.ldb * 4 * (GBN + 1) >= (1L << 31)) return 0;
     }
     (void)M;

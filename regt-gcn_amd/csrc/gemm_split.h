@@ -182,13 +182,34 @@ struct SplitCore : FastCore<true, REGION> {
     // end return 0 through the range check: no per-load guard), the slab's k offset as the instruction's scalar offset;
     // what is left per slab are four v_mad for the per-thread row offsets.  Requirements (host: uniform_ok in gemm.hip):
     // no region-masked segment, every K a multiple of 32, rows of a tile consecutive (rm.mul == 1).
+    // Region-masked segments (REGION kernels): the segment repeats once per DISTINCT region among the tile's rows (sorted
+    // list from tile_regions, copied to the unused iteration-table area by uniform_regions()); a row takes part in the
+    // repeat of its own region only -- its vector offset is out of range otherwise (one compare + select per row slot
+    // and slab).
     struct SegCursor { int s, ri, k0; };
+    int nreg_u;                // number of distinct regions in the tile (uniform path of REGION kernels)
     __device__ __forceinline__ const GemmSeg& cseg(int sidx) const { return S.seg[sidx]; }
+    __device__ __forceinline__ int seg_count(const GemmSeg& g) const {
+        if (REGION && (g.flags & SEG_REGION)) return nreg_u;
+        return (g.flags & SEG_REPEAT) ? g.nrep : 1;
+    }
+    __device__ __forceinline__ void uniform_regions() {
+        nreg_u = 0;
+        if (REGION) {
+            int* red = reinterpret_cast<int*>(lds);
+            const int* list = tile_regions<GBM>(S, rm, red, tid);
+            __syncthreads();
+            nreg_u = __builtin_amdgcn_readfirstlane(red[3]);
+            int* keep = reinterpret_cast<int*>(table);
+            if (tid < nreg_u) keep[tid] = list[tid];
+            __syncthreads();
+        }
+    }
     __device__ __forceinline__ int total_slabs() const {
         int n = 0;
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            if (q < S.nseg) n += ((S.seg[q].flags & SEG_REPEAT) ? S.seg[q].nrep : 1) * (S.seg[q].K / GBK);
+            if (q < S.nseg) n += seg_count(S.seg[q]) * (S.seg[q].K / GBK);
         return n;
     }
     __device__ __forceinline__ void cursor_next(SegCursor& c) const {
@@ -196,18 +217,20 @@ struct SplitCore : FastCore<true, REGION> {
         c.k0 += GBK;
         if (c.k0 >= g.K) {
             c.k0 = 0;
-            if (++c.ri >= ((g.flags & SEG_REPEAT) ? g.nrep : 1)) { c.ri = 0; ++c.s; }
+            if (++c.ri >= seg_count(g)) { c.ri = 0; ++c.s; }
         }
     }
     struct SrdsU { __amdgpu_buffer_rsrc_t a, b; int abf, va[2], vb[2], sa, sb; };
     __device__ __forceinline__ SrdsU make_u(const SegCursor& c, bool live) const {
         const GemmSeg& g = cseg(live ? c.s : 0);
         const bool rep = (g.flags & SEG_REPEAT) != 0;
+        const bool reg = REGION && (g.flags & SEG_REGION) != 0;
+        const int region = reg && live ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(table)[c.ri]) : -1;
         SrdsU d;
         d.abf = (g.flags & SEG_A_BF16) ? 1 : 0;
         const int lda_b = (int)g.lda * (d.abf ? 2 : 4), ldb_b = (int)g.ldb * 4;
         const char* ap = reinterpret_cast<const char*>(g.A) + (rep ? (long)c.ri * g.a_rep_stride * 4 : 0) + rm.base * lda_b;
-        const long boff = rep ? (long)c.ri * g.b_region_stride : 0;
+        const long boff = reg ? (long)region * g.b_region_stride : (rep ? (long)c.ri * g.b_region_stride : 0);
         const bool lowb = n0 < g.nsplit;
         const float* bp = lowb ? g.B0 + boff + (long)n0 * g.ldb : g.B1 + boff + (long)(n0 - g.nsplit) * g.ldb;
         const int blim = (lowb && g.nsplit < N ? g.nsplit : N) - n0, brows = blim < GBN ? blim : GBN;
@@ -219,6 +242,10 @@ struct SplitCore : FastCore<true, REGION> {
         } else {
             d.va[0] = (tid >> 2) * lda_b + (tid & 3) * 16;
             d.va[1] = d.va[0] + 64 * lda_b;
+            if (REGION && reg) {
+                d.va[0] = sreg[0] == region ? d.va[0] : (int)Base::SRD_OOB;
+                d.va[1] = sreg[1] == region ? d.va[1] : (int)Base::SRD_OOB;
+            }
         }
         d.vb[0] = (tid >> 2) * ldb_b + (tid & 3) * 16;
         d.vb[1] = d.vb[0] + 64 * ldb_b;
@@ -622,7 +649,8 @@ struct SplitCore : FastCore<true, REGION> {
         else run_t<false>(acc);
     }
     // scalar-descriptor path (no iteration table: plan() is not needed); host-checked eligibility
-    __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) const {
+    __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) {
+        uniform_regions();
         if (relu_a) run_u<true>(acc);
         else run_u<false>(acc);
     }
