@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     mode, nodes, out = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     dev = torch.device("cuda")
     R.load_library().regt_set_gemm_mode(mode)
-    F, T, O, regions = 8, 12, 1, 4
+    F, T, O, regions = int(os.environ.get("AB_F", "8")), 12, 1, 4
     g = R.data.synthetic_regional_graph(nodes, nodes * 8, regions, seed=3)
     graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index], [t.to(dev) for t in g.region_attr], nodes)
     torch.manual_seed(5)
