@@ -362,6 +362,87 @@ struct SplitCore : FastCore<true, REGION> {
     }
     __device__ __forceinline__ void compute(int h, f32x16 (&acc)[2][2]) const { mfmas(read_frags(h), acc); }
 
+    // ---- bf16-operand core (NP = 1): whole 32-k slabs per barrier ------------------------------------------------------------
+    // A bf16 MFMA half step is 4 x 32 = 128 matrix-pipe cycles: with the half-step schedule a tile of K = 288 pays 18 barriers
+    // and 18 LDS round trips for 2.3 k cycles of MFMA work (tools/wg_trace.py 2: K loop 15 us per tile).  One plane per
+    // operand leaves room for TWO full-slab buffers (4 half stages, 32 KB, inside the half-tile epilogue image): slab it is
+    // multiplied (8 MFMAs, 8 fragment reads) while slab it + 1 is stored into the other buffer and slab it + 2 requested --
+    // one barrier per 32 k.
+    __device__ __forceinline__ Frags read_frags_at(int stage) const {
+        const char* st = reinterpret_cast<const char*>(lds) + stage * STAGE_B;
+        const int lr = lane & 31, lh = lane >> 5;
+        Frags f;
+        if constexpr (NP == 1) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f.a[t][0] = *reinterpret_cast<const bf16x8*>(st + sp_off(wr * 64 + t * 32 + lr, lh));
+                f.b[t][0] = *reinterpret_cast<const bf16x8*>(st + OPER_B + sp_off(wc * 64 + t * 32 + lr, lh));
+            }
+        }
+        return f;
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void store_half_at(int stage, int h, const float4 (&ra)[4], const float4 (&rb)[4], int abf) const {
+        char* st = reinterpret_cast<char*>(lds) + stage * STAGE_B;
+        if (abf) *reinterpret_cast<float4*>(st + sp_off(tid >> 1, tid & 1)) = ra[h];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
+            if (!abf) {
+                float4 a = ra[h + 2 * j];
+                if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                split_store(st + off, a);
+            }
+            split_store(st + OPER_B + off, rb[h + 2 * j]);
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void run_u1(f32x16 (&acc)[2][2]) const {
+        const int nslab = total_slabs();
+        if (nslab == 0) return;
+        float4 ra[4], rb[4];
+        int held;
+        SegCursor c{0, 0, 0};
+        {
+            const SrdsU d = make_u(c, true);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+            held = d.abf;
+        }
+        store_half_at<RELU>(0, 0, ra, rb, held);
+        store_half_at<RELU>(1, 1, ra, rb, held);
+        {
+            const bool two = nslab > 1;
+            if (two) cursor_next(c);
+            const SrdsU d = make_u(c, two);
+            load_half(0, d, ra, rb);
+            load_half(1, d, ra, rb);
+            held = d.abf;
+        }
+        __syncthreads();
+        for (int it = 0; it < nslab; ++it) {
+            const int cur = 2 * (it & 1), nxt = 2 - cur;
+            const bool more = it + 1 < nslab, live = it + 2 < nslab;
+            if (live) cursor_next(c);
+            const SrdsU nx = make_u(c, live);
+            __builtin_amdgcn_sched_barrier(0);
+            const Frags f0 = read_frags_at(cur), f1 = read_frags_at(cur + 1);
+            if (more) {
+                store_half_at<RELU>(nxt, 0, ra, rb, held);
+                store_half_at<RELU>(nxt + 1, 1, ra, rb, held);
+            }
+            mfmas(f0, acc);
+            mfmas(f1, acc);
+            if (more) {
+                load_half(0, nx, ra, rb);
+                load_half(1, nx, ra, rb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            held = nx.abf;
+            __syncthreads();
+        }
+    }
+
     // store half hs of the next slab while the MFMAs of half hc of the current slab run: one MFMA, then a few of the
     // conversion VALU ops and now and then a plane write, so that a single wave keeps its SIMD's matrix pipe busy (a
     // bf16 32x32x16 MFMA occupies the pipe for 32 cycles = 8 issue slots).  The registers just stored are refilled
@@ -651,8 +732,13 @@ struct SplitCore : FastCore<true, REGION> {
     // scalar-descriptor path (no iteration table: plan() is not needed); host-checked eligibility
     __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) {
         uniform_regions();
-        if (relu_a) run_u<true>(acc);
-        else run_u<false>(acc);
+        if constexpr (NP == 1) {
+            if (relu_a) run_u1<true>(acc);
+            else run_u1<false>(acc);
+        } else {
+            if (relu_a) run_u<true>(acc);
+            else run_u<false>(acc);
+        }
     }
 };
 
