@@ -1,12 +1,16 @@
 // Dense contractions of the RegT-GCN pipeline on the matrix cores.
 //
-//   gemm_flat_fast_kernel<Epi, Core>   C = sum_seg A_seg B_seg^T with a fused epilogue (forward + data gradients);
-//                                      Core = FastCore (fp32 v_mfma_f32_32x32x2_f32, gemm_fast.h) or SplitCore (exact
-//                                      3-way bf16 split on v_mfma_f32_32x32x16_bf16, gemm_split.h; opt-in)
+//   gemm_flat_split_kernel<Epi, REGION, NP>  C = sum_seg A_seg B_seg^T with a fused epilogue (forward + data gradients) on the
+//                                      three-workgroup core SplitCore (gemm_split.h): NP = 0 fp32 planes on
+//                                      v_mfma_f32_32x32x2_f32 (the default), 3 = exact 3-way bf16 split, 1 = bf16 operands
+//                                      (v_mfma_f32_32x32x16_bf16); gemm_flat_split8_kernel: NP = 1 with bf16-stored activations
+//   gemm_flat_fast_kernel<Epi, Core>   the two-workgroup fp32 core FastCore (gemm_fast.h): weights stored [K][N],
+//                                      REGT_FP32_CORE=wide
 //   gemm_flat_small_kernel<Epi, ..>    the same with 64 x 64 tiles for problems of fewer than 128 big tiles (gemm_small.h)
 //   gemm_flat_kernel<Epi>              generic fallback (operands that are not 16-byte tileable)
-//   gemm_cand_flat_kernel<Core>        candidate state + GRU blend + attention-weighted sum over the T periods
-//   wgrad_kernel<BNW> / wgrad_split_kernel   out = P^T Q over row chunks (weight gradients), partial slabs
+//   gemm_cand_split_kernel<NP> / gemm_cand_split8_kernel   candidate state + GRU blend + attention-weighted sum over the T
+//                                      periods (gemm_cand_flat_kernel<Core>: small tiles / two-workgroup core)
+//   wgrad3_kernel / wgrad_kernel<BNW> / wgrad_split_kernel   out = P^T Q over row chunks (weight gradients), partial slabs
 //   wgrad_reduce(_multi)_kernel        deterministic reduction of the slabs (all of a backward pass in one launch)
 //   small_gemm_multi_kernel            strided batched C = A B for the (C x F)-sized weight compositions
 #include "kernels.h"

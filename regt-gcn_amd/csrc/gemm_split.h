@@ -8,13 +8,17 @@
 // v_mfma_f32_32x32x16_bf16 retires 16x the k-extent of v_mfma_f32_32x32x2_f32 in half the cycles: 6 bf16 MFMAs
 // replace 8 fp32 MFMAs per 16 k and take 192 instead of 512 matrix-pipe cycles.
 //
-// Opt-in (regt_set_gemm_mode / REGT_GEMM_MODE=bf16x3); the default path stays on the fp32 MFMA (gemm_fast.h).
+// The split is opt-in (regt_set_gemm_mode / REGT_GEMM_MODE=bf16x3).  The core itself is the default GEMM core of every
+// arithmetic since round 2: NP = 0 keeps the operands fp32 and multiplies on the fp32 MFMA (same results as gemm_fast.h's
+// two-workgroup core), NP = 1 rounds them to bf16 (REGT_GEMM_MODE=bf16).  Round-2 additions, further down: the compact LDS
+// layout with a half-tile epilogue (three workgroups per CU), slab descriptors in scalar registers (run_u / run_u1),
+// branch-free epilogue bodies for full tiles (vec_body_halves / vec8_body_halves).
 //
 // Same 128x128 tile, 2x2 waves, row map, iteration table, buffer-descriptor loads and LDS-staged epilogue as
 // FastCore<true, REGION> (B given as [N][K], k contiguous).  What changes is the K loop:
 //   * LDS holds bf16 planes: stage h (h = 0, 1) = the h-th 16-k half of the current 32-k slab, per operand three
 //     planes of 128 rows x 32 B, k-group bit swizzled by row bit 3 (sp_off: conflict-free ds_read_b128 AND
-//     ds_write_b64 without padding).  2 stages x 24,576 B, inside the fp32 core's footprint, 2 workgroups per CU;
+//     ds_write_b64 without padding).  2 stages x 24,576 B (NP = 3), three workgroups per CU with the compact layout;
 //   * a thread owns 2 float4 of A and 2 of B per half (row = tid/4 (+64), k-quad = tid%4 (+4 for the second half)),
 //     splits them while storing (v_cvt_pk_bf16_f32 + packed fp32 subtract: 9 VALU per element pair);
 //   * the two halves double-buffer each other:  compute(h0) | barrier | store next h0 | compute(h1) | barrier |
