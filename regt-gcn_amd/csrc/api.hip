@@ -159,6 +159,25 @@ int q_format(const void* ws) {
 }
 inline const float* byte_off(const float* p, long bytes) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + bytes); }
 
+// bf16 mode with bf16-stored activations: the GEMM weights get per-step bf16 copies in MFMA fragment order (SEG_B_FRAG: every
+// wave loads its B fragments straight into registers) when every K is a multiple of the 32-k slab
+bool weights_frag(const regt_dims& d) { return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced(); }
+struct WbPtrs { const float *U[3], *UT[3], *Gzr, *Gh, *A0, *Aall; long ar_stride; };
+WbPtrs wb_ptrs(const float* Wb, long C, long F, long R) {
+    const char* b = reinterpret_cast<const char*>(Wb);
+    WbPtrs w;
+    long o = 0;
+    for (int k = 0; k < 3; ++k) { w.U[k] = reinterpret_cast<const float*>(b + o); o += frag_bytes(C, C); }
+    for (int k = 0; k < 3; ++k) { w.UT[k] = reinterpret_cast<const float*>(b + o); o += frag_bytes(C, C); }
+    w.Gzr = reinterpret_cast<const float*>(b + o); o += frag_bytes(2 * C, F);
+    w.Gh = reinterpret_cast<const float*>(b + o); o += frag_bytes(C, F);
+    w.A0 = reinterpret_cast<const float*>(b + o); o += frag_bytes(C, F);
+    w.Aall = reinterpret_cast<const float*>(b + o);
+    w.ar_stride = frag_bytes(C, F);
+    (void)R;
+    return w;
+}
+
 GemmSeg make_seg(const float* A, long lda, const float* B0, const float* B1, long ldb, int nsplit, int K, bool bt,
                  int extra_flags = 0, long region_stride = 0) {
     GemmSeg s{};
@@ -180,6 +199,7 @@ struct Layout {
     // backward temporaries
     float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
     float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r) for the data-gradient GEMMs
+    float *Wb;   // fragment-order bf16 copies of the GEMM weights (bf16 mode)
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
     int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
     long slab_floats;
@@ -215,6 +235,9 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.czr = take(2 * C);
     L.ch = take(C);
     L.UT = take(3 * C * C);
+    // bf16 copies of the GEMM weights in MFMA fragment order (REGT_GEMM_MODE=bf16, weights_frag()): Uz, Ur, Uh, UT x 3 (C x C
+    // each), Gzr (2C x F), Gh (C x F), A0 (C x F), A_r (R x (C x F)); rows padded to 128 -- sized in floats
+    L.Wb = take((6 * frag_bytes(C, C) + frag_bytes(2 * C, F) + (2 + R) * frag_bytes(C, F)) / 4 + 64);
     L.dOH = take(N * C);
     L.d1 = take(N * H1);
     L.dhp = take(M * C);
@@ -385,13 +408,31 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     const float* A0 = d.regional ? L.A0 : p.cheb_w0;
     const float* Aall = d.regional ? L.Aall : p.cheb_w1;
     const float* bpr = d.regional ? L.bprime : p.cheb_bias;
+    const bool wfr = abf && weights_frag(d) && d.regional && !g.overlap;
+    const WbPtrs wb = wb_ptrs(L.Wb, C, F, R);
+    if (wfr) {
+        CvtBatch cb{};
+        cb.n = 0;
+        for (int k = 0; k < 3; ++k) cb.t[cb.n++] = CvtTask{p.gate_w[k] + C, 2L * C, C, C, const_cast<float*>(wb.U[k])};
+        cb.t[cb.n++] = CvtTask{L.Gzr, F, 2 * C, F, const_cast<float*>(wb.Gzr)};
+        cb.t[cb.n++] = CvtTask{L.Gh, F, C, F, const_cast<float*>(wb.Gh)};
+        cb.t[cb.n++] = CvtTask{A0, F, C, F, const_cast<float*>(wb.A0)};
+        cb.t[cb.n++] = CvtTask{Aall, F, R * C, F, const_cast<float*>(wb.Aall)};      // C % 128 == 0: region r starts at block row r C / 32
+        PROF("weights_bf16", st);
+        TRY(launch_cvt_bf16_frag(cb, st));
+    }
     // 2. regional embedding h = act(x A0^T + (L~ x) A_region^T + b')
     if (!h_ext) {
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(Xp, F, A0, nullptr, F, INT_MAX, F, true);
-        S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true,
-                            g.overlap ? SEG_REPEAT : (R > 1 ? SEG_REGION : 0), (long)C * F);
+        if (wfr) {
+            S.seg[0] = make_seg(Xp, F, wb.A0, nullptr, F, INT_MAX, F, true, SEG_B_FRAG);
+            S.seg[1] = make_seg(L.LX, F, wb.Aall, nullptr, F, INT_MAX, F, true, (R > 1 ? SEG_REGION : 0) | SEG_B_FRAG, wb.ar_stride);
+        } else {
+            S.seg[0] = make_seg(Xp, F, A0, nullptr, F, INT_MAX, F, true);
+            S.seg[1] = make_seg(L.LX, F, Aall, nullptr, F, INT_MAX, F, true,
+                                g.overlap ? SEG_REPEAT : (R > 1 ? SEG_REGION : 0), (long)C * F);
+        }
         S.seg[1].a_rep_stride = M * F;
         S.seg[1].nrep = R;
         S.node_region = g.node_region;
@@ -408,8 +449,13 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         GemmSegs S{};
         S.nseg = 2;
-        S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true, abf ? SEG_A_BF16 : 0);
-        S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
+        if (wfr) {
+            S.seg[0] = make_seg(H, C, wb.U[0], wb.U[1], C, C, C, true, SEG_A_BF16 | SEG_B_FRAG);
+            S.seg[1] = make_seg(L.AX, F, wb.Gzr, nullptr, F, INT_MAX, F, true, SEG_B_FRAG);
+        } else {
+            S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true, abf ? SEG_A_BF16 : 0);
+            S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
+        }
         S.row_div = T;
         EpiGates e{L.ZR, H, L.q, L.czr, C};
         e.q_bf16 = qbf; e.h_bf16 = abf; e.zr_bf16 = abf;
@@ -420,8 +466,13 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
     {
         CandArgs a{};
         a.S.nseg = 2;
-        a.S.seg[0] = make_seg(L.q, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, true, qbf ? SEG_A_BF16 : 0);
-        a.S.seg[1] = make_seg(L.AX, F, L.Gh, nullptr, F, INT_MAX, F, true);
+        if (wfr) {
+            a.S.seg[0] = make_seg(L.q, C, wb.U[2], nullptr, C, INT_MAX, C, true, (qbf ? SEG_A_BF16 : 0) | SEG_B_FRAG);
+            a.S.seg[1] = make_seg(L.AX, F, wb.Gh, nullptr, F, INT_MAX, F, true, SEG_B_FRAG);
+        } else {
+            a.S.seg[0] = make_seg(L.q, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, true, qbf ? SEG_A_BF16 : 0);
+            a.S.seg[1] = make_seg(L.AX, F, L.Gh, nullptr, F, INT_MAX, F, true);
+        }
         a.S.row_div = T;
         a.num_nodes = N; a.T = T; a.C = C;
         a.bias = L.ch; a.ZR = L.ZR; a.h = H; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
@@ -563,10 +614,20 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         PROF("transpose_gate_w", st);
         TRY(launch_transpose3(p.gate_w[2] + C, p.gate_w[0] + C, p.gate_w[1] + C, 3, L.UT, C, C, 2L * C, st));
     }
+    const bool wfr = abf && ibf && weights_frag(d) && d.regional;
+    const WbPtrs wb = wb_ptrs(L.Wb, C, F, R);
+    if (wfr) {
+        CvtBatch cb{};
+        cb.n = 3;
+        for (int k = 0; k < 3; ++k) cb.t[k] = CvtTask{L.UT + (long)k * C * C, C, C, C, const_cast<float*>(wb.UT[k])};
+        PROF("weights_bf16", st);
+        TRY(launch_cvt_bf16_frag(cb, st));
+    }
     {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
         GemmSegs S{};
         S.nseg = 1;
-        if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true, ibf ? SEG_A_BF16 : 0);
+        if (wfr) S.seg[0] = make_seg(L.dhp, C, wb.UT[0], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
+        else if (split) S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true, ibf ? SEG_A_BF16 : 0);
         else S.seg[0] = make_seg(L.dhp, C, p.gate_w[2] + C, nullptr, 2L * C, INT_MAX, C, false);
         S.row_div = T;
         EpiDgrad1 e{H, L.ZR, L.dOH, L.probs, L.dzr, DH, C, T};
@@ -577,7 +638,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
         GemmSegs S{};
         S.nseg = 2;
-        if (split) {
+        if (wfr) {
+            S.seg[0] = make_seg(L.dzr, 2L * C, wb.UT[1], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
+            S.seg[1] = make_seg(byte_off(L.dzr, 2L * C), 2L * C, wb.UT[2], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
+        } else if (split) {
             const int fl = ibf ? SEG_A_BF16 : 0;
             S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true, fl);
             S.seg[1] = make_seg(byte_off(L.dzr, (ibf ? 2L : 4L) * C), 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true, fl);

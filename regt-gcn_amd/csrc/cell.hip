@@ -281,6 +281,43 @@ __global__ __launch_bounds__(256) void transpose3_kernel(const float* s0, const 
         if (c0 + i < cols && r0 + tx < rows) out[(long)(c0 + i) * rows + r0 + tx] = tile[tx][i];
 }
 
+__global__ __launch_bounds__(256) void cvt_bf16_frag_kernel(CvtBatch b) {
+    int t = 0;
+    while (t + 1 < b.n && (int)blockIdx.x >= b.block_start[t + 1]) ++t;
+    const CvtTask k = b.t[t];
+    const int kg_per_row = k.cols / 8, rows_pad = (k.rows + 127) / 128 * 128;
+    const long idx = (long)(blockIdx.x - b.block_start[t]) * 256 + threadIdx.x;      // one 16-byte chunk: (row n, k-group kg)
+    if (idx >= (long)rows_pad * kg_per_row) return;
+    // chunk order of the destination: block (n / 32, kg / 2), inside it lane 32 (kg % 2) + n % 32
+    const long blk = idx / 64;
+    const int lane = (int)(idx % 64);
+    const int nb = (int)(blk / (k.cols / 16)), ks = (int)(blk % (k.cols / 16));
+    const int n = 32 * nb + (lane & 31), c = 16 * ks + 8 * (lane >> 5);
+    uint4 out = make_uint4(0, 0, 0, 0);
+    if (n < k.rows) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const float4 lo = *reinterpret_cast<const float4*>(k.src + (long)n * k.ld + c), hi = *reinterpret_cast<const float4*>(k.src + (long)n * k.ld + c + 4);
+        const f32x2_t p0 = {lo.x, lo.y}, p1 = {lo.z, lo.w}, p2 = {hi.x, hi.y}, p3 = {hi.z, hi.w};
+        out = make_uint4(__builtin_bit_cast(unsigned, __builtin_convertvector(p0, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(p1, bf16x2_t)),
+                         __builtin_bit_cast(unsigned, __builtin_convertvector(p2, bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(p3, bf16x2_t)));
+    }
+    reinterpret_cast<uint4*>(k.dst)[idx] = out;
+}
+int launch_cvt_bf16_frag(CvtBatch& b, hipStream_t st) {
+    REGT_CHECK_ARG(b.n >= 1 && b.n <= 8, "cvt_bf16_frag: %d tasks", b.n);
+    int blocks = 0;
+    for (int t = 0; t < b.n; ++t) {
+        REGT_CHECK_ARG(b.t[t].cols % 16 == 0 && b.t[t].ld % 4 == 0 && b.t[t].rows > 0, "cvt_bf16_frag: block %d: cols %% 16", t);
+        b.block_start[t] = blocks;
+        blocks += (int)(((long)((b.t[t].rows + 127) / 128 * 128) * (b.t[t].cols / 8) + 255) / 256);
+    }
+    b.block_start[b.n] = blocks;
+    hipLaunchKernelGGL(cvt_bf16_frag_kernel, dim3(blocks), dim3(256), 0, st, b);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
                       hipStream_t st) {
     REGT_CHECK_ARG(count >= 1 && count <= 3 && rows > 0 && cols > 0, "transpose3: bad argument");

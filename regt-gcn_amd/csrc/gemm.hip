@@ -766,7 +766,8 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, lo
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     WG_TRACE_T(t_a);
-    if (uni) core.run_uniform(acc, false);
+    if (uniform == 2) core.run_uniform_frag(acc, false);
+    else if (uni) core.run_uniform(acc, false);
     else core.run(acc, false);
     WG_TRACE_T(t_b);
     core.for_each_vec8_halves(acc, epi);
@@ -812,18 +813,25 @@ bool fp32_core_wide() {
 }
 
 // the K loop may keep its slab descriptors in scalar registers (SplitCore::run_u): every K a multiple of the 32-k slab, byte offsets of a tile's rows within 31 bits.  REGT_GEMM_DESC=table forces the LDS table.
-static int uniform_ok(const GemmSegs& S, long M) {
+bool gemm_desc_table_forced() {
     static int force_table = -1;
     if (force_table < 0) { const char* e = getenv("REGT_GEMM_DESC"); force_table = e && !strcmp(e, "table") ? 1 : 0; }
-    if (force_table) return 0;
+    return force_table == 1;
+}
+// 0: LDS table; 1: scalar descriptors; 2: scalar descriptors and every segment's weights in fragment order (SEG_B_FRAG)
+static int uniform_ok(const GemmSegs& S, long M) {
+    if (gemm_desc_table_forced()) return 0;
+    int frag = 0;
     for (int s = 0; s < S.nseg; ++s) {
         const GemmSeg& g = S.seg[s];
         if (g.K % GBK != 0 || g.K <= 0) return 0;
         if ((g.flags & SEG_REGION) && (g.flags & SEG_A_BF16)) return 0;       // bf16 rows are never region-masked
         if (g.lda * 4 * (GBM + 1) >= (1L << 31) || g.ldb * 4 * (GBN + 1) >= (1L << 31)) return 0;
+        if (g.flags & SEG_B_FRAG) ++frag;
     }
     (void)M;
-    return 1;
+    if (frag == 0) return 1;
+    return frag == S.nseg && gemm_mode() == 2 ? 2 : 0;
 }
 
 // 0: not eligible, else bit0 = BT, bit1 = has a region-masked segment, bit2 = relu on A
@@ -908,6 +916,8 @@ static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipSt
 template <class EpiF8, bool REGION>
 static int launch_split8(const GemmSegs& S, long M, int N, EpiF8 f, hipStream_t st) {
     REGT_CHECK_ARG(gemm_mode() == 2 && N % 8 == 0, "gemm: bf16-stored activations need REGT_GEMM_MODE=bf16 and N %% 8 == 0");
+    for (int q = 0; q < S.nseg; ++q)
+        REGT_CHECK_ARG(!(S.seg[q].flags & SEG_B_FRAG) || uniform_ok(S, M) == 2, "gemm: fragment-order weights need every segment in that order and K %% 32 == 0");
     const long tiles = (long)cdiv(M, GBM) * cdiv(N, GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
     hipLaunchKernelGGL((gemm_flat_split8_kernel<EpiF8, REGION>), dim3((unsigned)tiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, S, M, N, f, uniform_ok(S, M));
@@ -1425,7 +1435,8 @@ __global__ __launch_bounds__(256, 3) void gemm_cand_split8_kernel(CandArgs a, in
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (uniform) core.run_uniform(acc, false);
+    if (uniform == 2) core.run_uniform_frag(acc, false);
+    else if (uniform) core.run_uniform(acc, false);
     else core.run(acc, false);
     if (rm.nvalid == GBM && n0 + GBN <= a.C) cand8_epilogue<true>(a, core, acc, lds, rowtab, m0, n0, GBM, node0, t0);
     else cand8_epilogue<false>(a, core, acc, lds, rowtab, m0, n0, rm.nvalid, node0, t0);
@@ -1454,9 +1465,11 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_cand_split_kernel<3>), dim3((unsigned)ftiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, a, uniform_ok(a.S, M));
         else if (gemm_mode() == 1)
             hipLaunchKernelGGL((gemm_cand_flat_kernel<SplitCore<false, 3>>), dim3((unsigned)ftiles), dim3(256), G_FAST_LDS_BYTES, st, a);
-        else if (gemm_mode() == 2 && a.act_bf16 && a.C % 8 == 0 && M < (1L << 31) && !fp32_core_wide())
+        else if (gemm_mode() == 2 && a.act_bf16 && a.C % 8 == 0 && M < (1L << 31) && !fp32_core_wide()) {
+            for (int q = 0; q < a.S.nseg; ++q)
+                REGT_CHECK_ARG(!(a.S.seg[q].flags & SEG_B_FRAG) || uniform_ok(a.S, M) == 2, "candidate gemm: fragment-order weights need K %% 32 == 0");
             hipLaunchKernelGGL(gemm_cand_split8_kernel, dim3((unsigned)ftiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, a, uniform_ok(a.S, M));
-        else if (gemm_mode() == 2 && a.act_bf16) {
+        } else if (gemm_mode() == 2 && a.act_bf16) {
             static bool attr_done8 = false;
             REGT_CHECK_ARG(a.C % 8 == 0, "candidate gemm: bf16 storage needs C %% 8 == 0");
             if (int rc = set_lds_once(&gemm_cand_flat8_kernel, G_FAST_LDS_BYTES, &attr_done8)) return rc;

@@ -33,6 +33,10 @@ enum : int {
     SEG_VEC_B = 16,   // B rows may be read as aligned float4
     SEG_A_BF16 = 64,  // A holds bf16 elements (lda in elements); bf16-operand core only (REGT_GEMM_MODE=bf16): the GEMM-only
                       // intermediates q, dhp, dzp|drp are rounded once by their producer instead of by every consumer
+    SEG_B_FRAG = 128, // B0 / B1 point at per-step bf16 copies of the weights in MFMA FRAGMENT order (launch_cvt_bf16_frag): the
+                      // 1 KB block (n / 32, k / 16) holds, for lane = 32 ((k % 16) / 8) + n % 32, the 8 bf16 k = 8 (k / 8) .. + 7
+                      // of row n; a wave loads its B fragments straight into registers (no LDS); rows padded to 128 with
+                      // zeros; b_region_stride in bytes.  bf16-operand core on the scalar-descriptor path only.
     SEG_REPEAT = 32,  // unmasked repeat: rep r = 0..nrep-1 uses A + r*a_rep_stride and B + r*b_region_stride
                       // (overlapping regional graphs: one (L~_r x) operand and one composed weight per region)
 };

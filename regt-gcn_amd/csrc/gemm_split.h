@@ -224,7 +224,7 @@ struct SplitCore : FastCore<true, REGION> {
             if (++c.ri >= seg_count(g)) { c.ri = 0; ++c.s; }
         }
     }
-    struct SrdsU { __amdgpu_buffer_rsrc_t a, b; int abf, va[2], vb[2], sa, sb; };
+    struct SrdsU { __amdgpu_buffer_rsrc_t a, b; int abf, va[2], vb[2], sa, sb, bks; };   // bks: bytes between 32-column blocks (SEG_B_FRAG)
     __device__ __forceinline__ SrdsU make_u(const SegCursor& c, bool live) const {
         const GemmSeg& g = cseg(live ? c.s : 0);
         const bool rep = (g.flags & SEG_REPEAT) != 0;
@@ -236,10 +236,25 @@ struct SplitCore : FastCore<true, REGION> {
         const char* ap = reinterpret_cast<const char*>(g.A) + (rep ? (long)c.ri * g.a_rep_stride * 4 : 0) + rm.base * lda_b;
         const long boff = reg ? (long)region * g.b_region_stride : (rep ? (long)c.ri * g.b_region_stride : 0);
         const bool lowb = n0 < g.nsplit;
+        d.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ap), 0, live ? rm.nvalid * lda_b : 0, 0x00020000);
+        d.bks = 0;
+        if (NP == 1 && (g.flags & SEG_B_FRAG)) {
+            // weights in fragment order: 1 KB blocks (n / 32, k / 16); the tile's four 32-column blocks start at block row nl / 32
+            d.bks = (g.K / 16) * 1024;
+            const int nl = lowb ? n0 : n0 - g.nsplit;
+            const char* bp = reinterpret_cast<const char*>(lowb ? g.B0 : g.B1) + boff + (long)(nl / 32) * d.bks;
+            d.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(bp), 0, live ? 4 * d.bks : 0, 0x00020000);
+            d.vb[0] = 2 * wc * d.bks + lane * 16;
+            d.vb[1] = 0;
+            d.sb = (c.k0 / 16) * 1024;
+        } else {
         const float* bp = lowb ? g.B0 + boff + (long)n0 * g.ldb : g.B1 + boff + (long)(n0 - g.nsplit) * g.ldb;
         const int blim = (lowb && g.nsplit < N ? g.nsplit : N) - n0, brows = blim < GBN ? blim : GBN;
-        d.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ap), 0, live ? rm.nvalid * lda_b : 0, 0x00020000);
         d.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bp), 0, live ? brows * ldb_b : 0, 0x00020000);
+        d.vb[0] = (tid >> 2) * ldb_b + (tid & 3) * 16;
+        d.vb[1] = d.vb[0] + 64 * ldb_b;
+        d.sb = c.k0 * 4;
+        }
         if (NP == 1 && d.abf) {
             d.va[0] = (tid >> 1) * lda_b + (tid & 1) * 16;
             d.va[1] = 0;
@@ -251,10 +266,7 @@ struct SplitCore : FastCore<true, REGION> {
                 d.va[1] = sreg[1] == region ? d.va[1] : (int)Base::SRD_OOB;
             }
         }
-        d.vb[0] = (tid >> 2) * ldb_b + (tid & 3) * 16;
-        d.vb[1] = d.vb[0] + 64 * ldb_b;
         d.sa = c.k0 * (d.abf ? 2 : 4);
-        d.sb = c.k0 * 4;
         return d;
     }
     __device__ __forceinline__ void load_half(int h, const SrdsU& d, float4 (&ra)[4], float4 (&rb)[4]) const {
@@ -444,6 +456,110 @@ struct SplitCore : FastCore<true, REGION> {
             __builtin_amdgcn_sched_barrier(0);
             held = nx.abf;
             __syncthreads();
+        }
+    }
+
+    // ---- bf16-operand core, weights in fragment order (SEG_B_FRAG): the B fragments never touch LDS ----------------------------
+    // Timing experiments on the bf16 gate GEMM (tools/wg_trace.py 2): without ANY global load in the K loop it still took 12 of
+    // its 16 us per tile, without the MFMAs 14.5 -- the loop is bound by its LDS round trips and the conversion of the weight
+    // tile (per 32-k slab and wave: 4 + 2 ds_write, 8 ds_read_b128, 8 v_cvt_pk behind a barrier, for 8 MFMAs of 32 cycles).
+    // The weights are the same for every tile: they are copied once per step to bf16 in the order the MFMA wants them
+    // (launch_cvt_bf16_frag), and every wave loads its own four 1 KB fragments per slab with four coalesced 16-byte loads,
+    // one slab ahead, straight into the registers the MFMAs read.  LDS carries the A operand only.
+    struct BFrags { bf16x8 v[2][2]; };          // [16-k half][32-column block of the wave]
+    __device__ __forceinline__ void load_bfrags(const SrdsU& d, BFrags& b) const {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                b.v[h][ni] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(d.b, d.vb[0], d.sb + h * 1024 + ni * d.bks, 0));
+    }
+    __device__ __forceinline__ void load_a_half(int h, const SrdsU& d, float4 (&ra)[4]) const {
+        if (d.abf) {
+            ra[h] = buf_ld4(d.a, d.va[0], d.sa + 32 * h);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) ra[h + 2 * j] = buf_ld4(d.a, d.va[j], d.sa + 64 * h);
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void store_a_at(int stage, int h, const float4 (&ra)[4], int abf) const {
+        char* st = reinterpret_cast<char*>(lds) + stage * STAGE_B;
+        if (abf) *reinterpret_cast<float4*>(st + sp_off(tid >> 1, tid & 1)) = ra[h];
+        else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float4 a = ra[h + 2 * j];
+                if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+                split_store(st + sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8, a);
+            }
+        }
+    }
+    template <bool RELU>
+    __device__ __forceinline__ void run_u1f(f32x16 (&acc)[2][2]) const {
+        static_assert(NP == 1, "fragment-order weights: bf16-operand core only");
+        const int nslab = total_slabs();
+        if (nslab == 0) return;
+        float4 ra[4];
+        BFrags b0, b1;
+        int held;
+        SegCursor c{0, 0, 0};
+        {
+            const SrdsU d = make_u(c, true);
+            load_a_half(0, d, ra);
+            load_a_half(1, d, ra);
+            load_bfrags(d, b0);
+            held = d.abf;
+        }
+        store_a_at<RELU>(0, 0, ra, held);
+        store_a_at<RELU>(1, 1, ra, held);
+        {
+            const bool two = nslab > 1;
+            if (two) cursor_next(c);
+            const SrdsU d = make_u(c, two);
+            load_a_half(0, d, ra);
+            load_a_half(1, d, ra);
+            load_bfrags(d, b1);
+            held = d.abf;
+        }
+        __syncthreads();
+        // slab it: A in LDS buffer it & 1, its B fragments in bc; registers ra / bn hold slab it + 1; slab it + 2 is requested
+        auto step = [&](int it, const BFrags& bc, BFrags& bn_out) {
+            const int cur = 2 * (it & 1), nxt = 2 - cur;
+            const bool more = it + 1 < nslab, live = it + 2 < nslab;
+            if (live) cursor_next(c);
+            const SrdsU nx = make_u(c, live);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* st = reinterpret_cast<const char*>(lds) + cur * STAGE_B;
+            const int lr = lane & 31, lh = lane >> 5;
+            bf16x8 fa[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[h][t] = *reinterpret_cast<const bf16x8*>(st + h * STAGE_B + sp_off(wr * 64 + t * 32 + lr, lh));
+            if (more) {
+                store_a_at<RELU>(nxt, 0, ra, held);
+                store_a_at<RELU>(nxt + 1, 1, ra, held);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][mt], bc.v[h][nt], acc[mt][nt], 0, 0, 0);
+            if (more) {
+                load_a_half(0, nx, ra);
+                load_a_half(1, nx, ra);
+            }
+            load_bfrags(nx, bn_out);        // the fragments of slab it + 2 replace those of slab it (dead descriptor: zeros)
+            __builtin_amdgcn_sched_barrier(0);
+            held = nx.abf;
+            __syncthreads();
+        };
+        for (int it = 0; it < nslab; it += 2) {
+            step(it, b0, b0);
+            if (it + 1 < nslab) step(it + 1, b1, b1);
         }
     }
 
@@ -734,6 +850,14 @@ struct SplitCore : FastCore<true, REGION> {
         else run_t<false>(acc);
     }
     // scalar-descriptor path (no iteration table: plan() is not needed); host-checked eligibility
+    // scalar descriptors + weights in fragment order (every segment SEG_B_FRAG; host-checked)
+    __device__ __forceinline__ void run_uniform_frag(f32x16 (&acc)[2][2], bool relu_a) {
+        uniform_regions();
+        if constexpr (NP == 1) {
+            if (relu_a) run_u1f<true>(acc);
+            else run_u1f<false>(acc);
+        }
+    }
     __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) {
         uniform_regions();
         if constexpr (NP == 1) {

@@ -209,6 +209,13 @@ int gemm_mode();
 void set_gemm_mode(int mode);
 bool fp32_core_wide();   // REGT_FP32_CORE=wide (A/B timing of the two fp32 GEMM cores)
 
+// fp32 -> bf16 (round to nearest even) copies of up to 8 weight blocks in MFMA fragment order (SEG_B_FRAG), one launch:
+// block t = rows x cols (cols % 16 == 0) at src with leading dimension ld; dst holds ceil(rows / 128) * 128 rows (zero padded)
+struct CvtTask { const float* src; long ld; int rows, cols; void* dst; };
+struct CvtBatch { int n; CvtTask t[8]; int block_start[9]; };
+int launch_cvt_bf16_frag(CvtBatch& b, hipStream_t st);
+inline long frag_bytes(long rows, long cols) { return ((rows + 127) / 128) * 128 * cols * 2; }
+bool gemm_desc_table_forced();     // REGT_GEMM_DESC=table
 int launch_transpose3(const float* s0, const float* s1, const float* s2, int count, float* dst, int rows, int cols, long ld,
                       hipStream_t st);   // dst[b] = src[b]^T, b < count <= 3
 // last head layer for output_dim <= 4 as row-wise fp32 kernels (cell.hip)
