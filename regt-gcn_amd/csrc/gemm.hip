@@ -822,13 +822,19 @@ bool gemm_desc_table_forced() {
 static int uniform_ok(const GemmSegs& S, long M) {
     if (gemm_desc_table_forced()) return 0;
     int frag = 0;
+    long slabs = 0;
     for (int s = 0; s < S.nseg; ++s) {
         const GemmSeg& g = S.seg[s];
         if (g.K % GBK != 0 || g.K <= 0) return 0;
         if ((g.flags & SEG_REGION) && (g.flags & SEG_A_BF16)) return 0;       // bf16 rows are never region-masked
         if (g.lda * 4 * (GBM + 1) >= (1L << 31) || g.ldb * 4 * (GBN + 1) >= (1L << 31)) return 0;
         if (g.flags & SEG_B_FRAG) ++frag;
+        // the bf16-operand core keeps the tile's slab descriptors in LDS, 64 at most (SplitCore::plan_u)
+        const long reps = (g.flags & SEG_REGION) ? std::min<long>(S.num_regions > 0 ? S.num_regions : 1, GBM / (S.row_div > 0 ? S.row_div : 1) + 2)
+                                                 : ((g.flags & SEG_REPEAT) ? g.nrep : 1);
+        slabs += reps * (g.K / GBK);
     }
+    if (gemm_mode() == 2 && slabs > 64) return 0;
     (void)M;
     if (frag == 0) return 1;
     return frag == S.nseg && gemm_mode() == 2 ? 2 : 0;

@@ -413,14 +413,12 @@ struct SplitCore : FastCore<true, REGION> {
         }
     }
     template <bool RELU>
-    __device__ __forceinline__ void run_u1(f32x16 (&acc)[2][2]) const {
-        const int nslab = total_slabs();
+    __device__ __forceinline__ void run_u1(f32x16 (&acc)[2][2], int nslab) const {
         if (nslab == 0) return;
         float4 ra[4], rb[4];
         int held;
-        SegCursor c{0, 0, 0};
         {
-            const SrdsU d = make_u(c, true);
+            const SrdsU d = fetch_u(0, true);
             load_half(0, d, ra, rb);
             load_half(1, d, ra, rb);
             held = d.abf;
@@ -429,8 +427,7 @@ struct SplitCore : FastCore<true, REGION> {
         store_half_at<RELU>(1, 1, ra, rb, held);
         {
             const bool two = nslab > 1;
-            if (two) cursor_next(c);
-            const SrdsU d = make_u(c, two);
+            const SrdsU d = fetch_u(1, two);
             load_half(0, d, ra, rb);
             load_half(1, d, ra, rb);
             held = d.abf;
@@ -439,8 +436,7 @@ struct SplitCore : FastCore<true, REGION> {
         for (int it = 0; it < nslab; ++it) {
             const int cur = 2 * (it & 1), nxt = 2 - cur;
             const bool more = it + 1 < nslab, live = it + 2 < nslab;
-            if (live) cursor_next(c);
-            const SrdsU nx = make_u(c, live);
+            const SrdsU nx = fetch_u(it + 2, live);
             __builtin_amdgcn_sched_barrier(0);
             const Frags f0 = read_frags_at(cur), f1 = read_frags_at(cur + 1);
             if (more) {
@@ -457,6 +453,97 @@ struct SplitCore : FastCore<true, REGION> {
             held = nx.abf;
             __syncthreads();
         }
+    }
+
+    // ---- tile-final slab descriptors in LDS (bf16-operand core) ------------------------------------------------------------------
+    // make_u() reads the segment's fields from the kernel arguments with dynamically indexed scalar loads: ~10 DEPENDENT s_load +
+    // s_waitcnt pairs per slab, ~2500 cycles.  Behind 2048-cycle fp32 half steps that is free; behind the 256 MFMA cycles of a
+    // bf16 slab it WAS the K loop (13.8 of the gate GEMM's 19 us per tile).  For NP = 1 the descriptors of all slabs of the tile
+    // are therefore computed once, one thread per slab, into the (otherwise unused) iteration-table area; the loop fetches
+    // slab it + 2's twelve dwords with three broadcast ds_read_b128 and v_readfirstlane.
+    struct UDesc { unsigned a_lo, a_hi, b_lo, b_hi; int a_rec, b_rec, lda_b, ldb_b, sa, sb, bks, fmt; };   // fmt: bit 0 abf, bit 1 frag
+    static_assert(sizeof(UDesc) == 48 && G_MAX_ITERS * sizeof(ItDesc) >= 64 * sizeof(UDesc), "descriptor table fits the iteration table");
+    __device__ __forceinline__ UDesc* utab() const { return reinterpret_cast<UDesc*>(reinterpret_cast<char*>(table) + 1024); }   // after the region list
+    __device__ __forceinline__ int plan_u() {
+        uniform_regions();
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            if (q < S.nseg) {
+                const GemmSeg& g = S.seg[q];
+                const bool rep = (g.flags & SEG_REPEAT) != 0, reg = REGION && (g.flags & SEG_REGION) != 0;
+                const int cnt = seg_count(g), nk = g.K / GBK, local = tid - n;
+                if (local >= 0 && local < cnt * nk && tid < 64) {
+                    const int ri = local / nk, k0 = (local - ri * nk) * GBK;
+                    const int region = reg ? reinterpret_cast<const int*>(table)[ri] : -1;
+                    UDesc u;
+                    const int abf = (g.flags & SEG_A_BF16) ? 1 : 0, frag = (g.flags & SEG_B_FRAG) ? 1 : 0;
+                    u.lda_b = (int)g.lda * (abf ? 2 : 4);
+                    u.ldb_b = (int)g.ldb * 4;
+                    const unsigned long long ap = reinterpret_cast<unsigned long long>(g.A) + (rep ? (long)ri * g.a_rep_stride * 4 : 0) + rm.base * u.lda_b;
+                    const long boff = reg ? (long)region * g.b_region_stride : (rep ? (long)ri * g.b_region_stride : 0);
+                    const bool lowb = n0 < g.nsplit;
+                    unsigned long long bp;
+                    if (frag) {
+                        u.bks = (g.K / 16) * 1024;
+                        const int nl = lowb ? n0 : n0 - g.nsplit;
+                        bp = reinterpret_cast<unsigned long long>(lowb ? g.B0 : g.B1) + boff + (long)(nl / 32) * u.bks;
+                        u.b_rec = 4 * u.bks;
+                        u.sb = (k0 / 16) * 1024;
+                    } else {
+                        u.bks = 0;
+                        bp = reinterpret_cast<unsigned long long>(lowb ? g.B0 + boff + (long)n0 * g.ldb : g.B1 + boff + (long)(n0 - g.nsplit) * g.ldb);
+                        const int blim = (lowb && g.nsplit < N ? g.nsplit : N) - n0;
+                        u.b_rec = (blim < GBN ? blim : GBN) * u.ldb_b;
+                        u.sb = k0 * 4;
+                    }
+                    u.a_lo = (unsigned)ap; u.a_hi = (unsigned)(ap >> 32); u.b_lo = (unsigned)bp; u.b_hi = (unsigned)(bp >> 32);
+                    u.a_rec = rm.nvalid * u.lda_b;
+                    u.sa = k0 * (abf ? 2 : 4);
+                    u.fmt = abf | (frag << 1) | ((region + 1) << 8);
+                    utab()[tid] = u;
+                }
+                n += cnt * nk;
+            }
+        }
+        __syncthreads();
+        return n;
+    }
+    // descriptor of slab `it` from the table (dead: num_records 0); region-masked rows get an out-of-range offset
+    __device__ __forceinline__ SrdsU fetch_u(int it, bool live) const {
+        const int* w = reinterpret_cast<const int*>(utab() + (live ? it : 0));
+        const int4 w0 = *reinterpret_cast<const int4*>(w), w1 = *reinterpret_cast<const int4*>(w + 4), w2 = *reinterpret_cast<const int4*>(w + 8);
+#define RFL_(x) __builtin_amdgcn_readfirstlane(x)
+        const unsigned long long ap = ((unsigned long long)(unsigned)RFL_(w0.y) << 32) | (unsigned)RFL_(w0.x);
+        const unsigned long long bp = ((unsigned long long)(unsigned)RFL_(w0.w) << 32) | (unsigned)RFL_(w0.z);
+        const int a_rec = RFL_(w1.x), b_rec = RFL_(w1.y), lda_b = RFL_(w1.z), ldb_b = RFL_(w1.w);
+        const int fmt = RFL_(w2.w);
+        SrdsU d;
+        d.sa = RFL_(w2.x); d.sb = RFL_(w2.y); d.bks = RFL_(w2.z);
+#undef RFL_
+        d.abf = fmt & 1;
+        const int region = (fmt >> 8) - 1;
+        d.a = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(ap), 0, live ? a_rec : 0, 0x00020000);
+        d.b = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(bp), 0, live ? b_rec : 0, 0x00020000);
+        if (d.abf) {
+            d.va[0] = (tid >> 1) * lda_b + (tid & 1) * 16;
+            d.va[1] = 0;
+        } else {
+            d.va[0] = (tid >> 2) * lda_b + (tid & 3) * 16;
+            d.va[1] = d.va[0] + 64 * lda_b;
+            if (REGION && region >= 0) {
+                d.va[0] = sreg[0] == region ? d.va[0] : (int)Base::SRD_OOB;
+                d.va[1] = sreg[1] == region ? d.va[1] : (int)Base::SRD_OOB;
+            }
+        }
+        if (fmt & 2) {
+            d.vb[0] = 2 * wc * d.bks + lane * 16;
+            d.vb[1] = 0;
+        } else {
+            d.vb[0] = (tid >> 2) * ldb_b + (tid & 3) * 16;
+            d.vb[1] = d.vb[0] + 64 * ldb_b;
+        }
+        return d;
     }
 
     // ---- bf16-operand core, weights in fragment order (SEG_B_FRAG): the B fragments never touch LDS ----------------------------
@@ -496,16 +583,14 @@ struct SplitCore : FastCore<true, REGION> {
         }
     }
     template <bool RELU>
-    __device__ __forceinline__ void run_u1f(f32x16 (&acc)[2][2]) const {
+    __device__ __forceinline__ void run_u1f(f32x16 (&acc)[2][2], int nslab) const {
         static_assert(NP == 1, "fragment-order weights: bf16-operand core only");
-        const int nslab = total_slabs();
         if (nslab == 0) return;
         float4 ra[4];
         BFrags b0, b1;
         int held;
-        SegCursor c{0, 0, 0};
         {
-            const SrdsU d = make_u(c, true);
+            const SrdsU d = fetch_u(0, true);
             load_a_half(0, d, ra);
             load_a_half(1, d, ra);
             load_bfrags(d, b0);
@@ -515,8 +600,7 @@ struct SplitCore : FastCore<true, REGION> {
         store_a_at<RELU>(1, 1, ra, held);
         {
             const bool two = nslab > 1;
-            if (two) cursor_next(c);
-            const SrdsU d = make_u(c, two);
+            const SrdsU d = fetch_u(1, two);
             load_a_half(0, d, ra);
             load_a_half(1, d, ra);
             load_bfrags(d, b1);
@@ -527,8 +611,7 @@ struct SplitCore : FastCore<true, REGION> {
         auto step = [&](int it, const BFrags& bc, BFrags& bn_out) {
             const int cur = 2 * (it & 1), nxt = 2 - cur;
             const bool more = it + 1 < nslab, live = it + 2 < nslab;
-            if (live) cursor_next(c);
-            const SrdsU nx = make_u(c, live);
+            const SrdsU nx = fetch_u(it + 2, live);
             __builtin_amdgcn_sched_barrier(0);
             const char* st = reinterpret_cast<const char*>(lds) + cur * STAGE_B;
             const int lr = lane & 31, lh = lane >> 5;
@@ -852,18 +935,19 @@ struct SplitCore : FastCore<true, REGION> {
     // scalar-descriptor path (no iteration table: plan() is not needed); host-checked eligibility
     // scalar descriptors + weights in fragment order (every segment SEG_B_FRAG; host-checked)
     __device__ __forceinline__ void run_uniform_frag(f32x16 (&acc)[2][2], bool relu_a) {
-        uniform_regions();
         if constexpr (NP == 1) {
-            if (relu_a) run_u1f<true>(acc);
-            else run_u1f<false>(acc);
+            const int nslab = plan_u();
+            if (relu_a) run_u1f<true>(acc, nslab);
+            else run_u1f<false>(acc, nslab);
         }
     }
     __device__ __forceinline__ void run_uniform(f32x16 (&acc)[2][2], bool relu_a) {
-        uniform_regions();
         if constexpr (NP == 1) {
-            if (relu_a) run_u1<true>(acc);
-            else run_u1<false>(acc);
+            const int nslab = plan_u();
+            if (relu_a) run_u1<true>(acc, nslab);
+            else run_u1<false>(acc, nslab);
         } else {
+            uniform_regions();
             if (relu_a) run_u<true>(acc);
             else run_u<false>(acc);
         }
