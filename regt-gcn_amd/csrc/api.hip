@@ -161,7 +161,9 @@ inline const float* byte_off(const float* p, long bytes) { return reinterpret_ca
 
 // bf16 mode with bf16-stored activations: the GEMM weights get per-step bf16 copies in MFMA fragment order (SEG_B_FRAG: every
 // wave loads its B fragments straight into registers) when every K is a multiple of the 32-k slab
-bool weights_frag(const regt_dims& d) { return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced(); }
+bool weights_frag(const regt_dims& d) {
+    return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced() && !fp32_core_wide();
+}
 struct WbPtrs { const float *U[3], *UT[3], *Gzr, *Gh, *A0, *Aall; long ar_stride; };
 WbPtrs wb_ptrs(const float* Wb, long C, long F, long R) {
     const char* b = reinterpret_cast<const char*>(Wb);

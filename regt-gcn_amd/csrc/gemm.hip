@@ -1476,6 +1476,8 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
                 REGT_CHECK_ARG(!(a.S.seg[q].flags & SEG_B_FRAG) || uniform_ok(a.S, M) == 2, "candidate gemm: fragment-order weights need K %% 32 == 0");
             hipLaunchKernelGGL(gemm_cand_split8_kernel, dim3((unsigned)ftiles), dim3(256), SplitGeom<1>::LDS_BYTES, st, a, uniform_ok(a.S, M));
         } else if (gemm_mode() == 2 && a.act_bf16) {
+            for (int q = 0; q < a.S.nseg; ++q)
+                REGT_CHECK_ARG(!(a.S.seg[q].flags & SEG_B_FRAG), "candidate gemm: fragment-order weights need the three-workgroup kernel");
             static bool attr_done8 = false;
             REGT_CHECK_ARG(a.C % 8 == 0, "candidate gemm: bf16 storage needs C %% 8 == 0");
             if (int rc = set_lds_once(&gemm_cand_flat8_kernel, G_FAST_LDS_BYTES, &attr_done8)) return rc;
