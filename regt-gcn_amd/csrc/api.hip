@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/regtgcn.h"
+#include <algorithm>
 #include "kernels.h"
 
 namespace regt {
@@ -162,7 +163,11 @@ inline const float* byte_off(const float* p, long bytes) { return reinterpret_ca
 // bf16 mode with bf16-stored activations: the GEMM weights get per-step bf16 copies in MFMA fragment order (SEG_B_FRAG: every
 // wave loads its B fragments straight into registers) when every K is a multiple of the 32-k slab
 bool weights_frag(const regt_dims& d) {
-    return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced() && !fp32_core_wide();
+    // ... and every GEMM of the step fits the 64-slab descriptor table of the bf16-operand core (SplitCore::plan_u): the
+    // regional embedding repeats its K = F segment once per region a 128-row tile can meet, the gate data gradient has K = 2C
+    const long reg_slabs = (long)(std::min<long>(d.R, 128 / d.T + 2) + 1) * (d.F / 32);
+    return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced() && !fp32_core_wide() &&
+           reg_slabs <= 64 && (2L * d.C + d.F) / 32 <= 64;
 }
 struct WbPtrs { const float *U[3], *UT[3], *Gzr, *Gh, *A0, *Aall; long ar_stride; };
 WbPtrs wb_ptrs(const float* Wb, long C, long F, long R) {
