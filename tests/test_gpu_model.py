@@ -132,7 +132,10 @@ def _synthetic(n, e, regions, f, t, seed):
                                               (2000, 16000, 64, 8, 6, 1),      # 64 regions = the 8-GPU global region count
                                               (1200, 9000, 4, 64, 12, 1),      # feat_dim 64 (BASELINE configs[4])
                                               (2048, 20000, 64, 64, 12, 1),    # feat_dim 64 AND 64 regions: the configs[4] shapes at fp32 1e-5
-                                              (600, 4000, 3, 7, 5, 2), (500, 3000, 2, 10, 4, 1)])   # F not a multiple of 4: padded staging
+                                              (600, 4000, 3, 7, 5, 2), (500, 3000, 2, 10, 4, 1),    # F not a multiple of 4: padded staging
+                                              # period counts at the ends of what the candidate kernel's 64-row halves see: one row per
+                                              # node, and nodes of 48 rows that straddle halves and tiles (at most two partial sums each)
+                                              (9000, 45000, 3, 32, 1, 1), (400, 3000, 2, 32, 48, 1)])
 def test_regt_matches_oracle_on_synthetic_regional_graph(R, arith, n, e, regions, f, t, o):
     ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n)
     y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
