@@ -71,7 +71,8 @@ def test_bf16_wgrad_is_the_rounded_operand_product(bf16_mode, m, n, k):
 
 
 # (nodes, edges, regions, F, T, O): F = 64 and 64 regions are the BASELINE configs[4] shapes; the first row is a cfg-3 shape
-SHAPES = [(1500, 15000, 8, 32, 12, 1), (2048, 20000, 64, 64, 12, 1), (1200, 9000, 4, 64, 12, 3)]
+SHAPES = [(1500, 15000, 8, 32, 12, 1), (2048, 20000, 64, 64, 12, 1), (1200, 9000, 4, 64, 12, 3),
+          (9000, 45000, 3, 32, 1, 1), (400, 3000, 2, 32, 48, 1)]     # one period; nodes of 48 rows across the 64-row halves
 
 
 def _models(R, n, e, regions, f, t, o):
