@@ -1,0 +1,34 @@
+"""The A/B switches of DESIGN.md section 6b select other kernels for the same arithmetic: each must reproduce the default
+path's forward + backward on one seeded problem (tools/ab_libs.py runs every configuration in its own process -- the
+switches are read once per process)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "regt-gcn_amd", "lib")
+
+
+def _ab(spec_b, mode, nodes, feat):
+    env = dict(os.environ, AB_F=str(feat))
+    env.pop("REGT_LIB_DIR", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_libs.py"), LIB, LIB + ":" + spec_b, str(mode), str(nodes)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = re.findall(r"^(\S+)\s+max\|a-b\| (\S+)\s+max\|a\| (\S+)$", out.stdout, flags=re.M)
+    assert len(rows) > 10, out.stdout[-2000:]
+    return [(name, float(d), float(a)) for name, d, a in rows]
+
+
+@pytest.mark.parametrize("switch,mode,rel", [
+    ("REGT_GEMM_DESC=table", 0, 0.0),        # same kernels, descriptors from the LDS table: bit-identical
+    ("REGT_GEMM_DESC=table", 2, 0.0),        # bf16: also turns the fragment-order weights off -- same rounding, same sums
+    ("REGT_FP32_CORE=wide", 0, 1e-5),        # two-workgroup kernels: a node's two partial sums are added in another order
+])
+def test_switch_reproduces_default(switch, mode, rel):
+    for name, diff, scale in _ab(switch, mode, 3000, 32):
+        assert diff <= rel * scale + (0.0 if rel == 0.0 else 1e-9), (switch, mode, name, diff, scale)
