@@ -2338,14 +2338,17 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 // a fixed xor-shuffle tree, so the order of the additions is fixed (deterministic) and small outputs
 // (the C x F gradients) still fill the chip.
 __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long block, long nblocks) {
+    // A workgroup owns 32 consecutive output elements; its eight 32-lane groups each sum every eighth chunk of them (a wave
+    // reads two chunks x 128 contiguous bytes per step -- with the eight partial sums of an element in ADJACENT lanes a wave
+    // touched eight chunks x 32 bytes), and the eight partial sums meet in LDS in the association of the former xor-shuffle
+    // tree: ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  Results are bit-identical to the shuffle version.
+    __shared__ float part[8][33];
     const long per = (long)a.Nout * a.Nin;
     const long total = per * a.ngroups;
     const long ncs = a.colsum_out ? a.ncolsum : 0;
-    const int sub = threadIdx.x & 7;
-    const long stride = nblocks * 256 / 8;
-    long idx = (block * 256 + threadIdx.x) / 8;
-    long wfirst = idx - (threadIdx.x % 64) / 8;
-    for (; wfirst < total + ncs; wfirst += stride, idx += stride) {
+    const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
+    for (long base = block * 32; base < total + ncs; base += nblocks * 32) {
+        const long idx = base + el;
         const bool valid = idx < total + ncs;
         float s = 0.f;
         int g = 0;
@@ -2355,16 +2358,26 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long
                 g = (int)(idx / per);
                 e = idx - (long)g * per;
                 const long se = a.slab_ld ? (e / a.Nin) * a.slab_ld + e % a.Nin : e;
-                for (int c = sub; c < a.nchunks; c += 8)
-                    if (!a.chunk_group || a.chunk_group[c] == g + a.group_base) s += a.slab[(long)c * a.slab_stride + a.elem_offset + se];
+                const float* p = a.slab + a.elem_offset + se;
+                int c = sub;
+                if (!a.chunk_group) {
+                    // four loads in flight, added in chunk order (the association of the plain loop)
+                    for (; c + 24 < a.nchunks; c += 32) {
+                        const float v0 = p[(long)c * a.slab_stride], v1 = p[(long)(c + 8) * a.slab_stride];
+                        const float v2 = p[(long)(c + 16) * a.slab_stride], v3 = p[(long)(c + 24) * a.slab_stride];
+                        s += v0; s += v1; s += v2; s += v3;
+                    }
+                }
+                for (; c < a.nchunks; c += 8)
+                    if (!a.chunk_group || a.chunk_group[c] == g + a.group_base) s += p[(long)c * a.slab_stride];
             } else {
                 for (int c = sub; c < a.nchunks; c += 8) s += a.slab[(long)c * a.slab_stride + a.colsum_offset + (idx - total)];
             }
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
+        part[sub][el] = s;
+        __syncthreads();
         if (valid && sub == 0) {
+            s = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) + ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
             if (idx < total) {
                 const int i = (int)(e / a.Nin), j = (int)(e % a.Nin);
                 float* o = a.out + (long)g * a.group_stride + (long)i * a.ldo + j;
@@ -2374,6 +2387,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long
                 a.colsum_out[i] = a.accumulate ? a.colsum_out[i] + s : s;
             }
         }
+        __syncthreads();
     }
 }
 
