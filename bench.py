@@ -248,8 +248,9 @@ def stage_kernel(stage, mode):
             pats.insert(0, f"gemm_flat_split8_kernel<regt::{epi}8F, false>")
         return pats
     if stage == "gemm_candidate":
-        return {0: ["gemm_cand_flat_kernel<regt::FastCore"], 1: ["gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
-                2: ["gemm_cand_flat8_kernel", "gemm_cand_flat_kernel<regt::SplitCore<false, 1>"]}[mode]
+        return {0: ["gemm_cand_split_kernel<0>", "gemm_cand_flat_kernel<regt::FastCore"],
+                1: ["gemm_cand_split_kernel<3>", "gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
+                2: ["gemm_cand_split8_kernel", "gemm_cand_flat8_kernel", "gemm_cand_flat_kernel<regt::SplitCore<false, 1>"]}[mode]
     if stage in ("wgrad_Uzr", "wgrad_Uh"):
         return ["wgrad_kernel<128"] if mode == 0 else ["wgrad_split_kernel"]
     if stage == "cell_bwd":
