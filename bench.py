@@ -362,14 +362,20 @@ def main():
         shard = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, gnodes, owner_bounds, region_owner,
                                    rank, vworld, dev)
         graph = shard.graph
+        # bf16 arithmetic at the shape the fused forward covers: the rank packs (and exchanges) its rows as bf16
+        rows_bf16 = mode == 2 and F == 64 and os.environ.get("REGT_XBF", "1") != "0"
         if shard_of_8:          # no peers: own rows packed once per snapshot, halo rows = random data (input values only)
             ext = []
             for x in xs:
                 buf = torch.rand(shard.topo.x_rows, T, F, device=dev)
-                R.ops.pack_x_into(x, buf)
+                if rows_bf16:
+                    buf = buf.to(torch.bfloat16)
+                    R.ops.pack_x_bf16_into(x, buf)
+                else:
+                    R.ops.pack_x_into(x, buf)
                 ext.append(buf)
         else:
-            pipe = R.dist.HaloPipeline(shard, T, F, dev)
+            pipe = R.dist.HaloPipeline(shard, T, F, dev, dtype=torch.bfloat16 if rows_bf16 else torch.float32)
     del g
     opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)   # run.py:145
     params = list(model.parameters())

@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 4
+#define REGT_ABI_VERSION 5
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -81,9 +81,19 @@ int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* va
 int32_t regt_spmm_dual(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const float* X,
                        float* YA, float* YL, int32_t num_nodes, int32_t width, regt_stream_t stream);
 
+/* The same with bf16 rows in and out (REGT_GEMM_MODE=bf16: x, A_hat x and L~ x only ever feed bf16 matrix-core operands
+ * there): X is (x_rows >= N) x width bf16 -- own rows first, then the halo rows of a region shard --, YA / YL are N x width
+ * bf16; fp32 accumulation in CSR order, one rounding (to nearest even) per output element; width % 64 == 0. */
+int32_t regt_spmm_dual_bf16(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const void* X,
+                            void* YA, void* YL, int32_t num_nodes, int32_t x_rows, int32_t width, regt_stream_t stream);
+
 /* Snapshot layout change (N,F,T) time-innermost (load_dataset.py:451-457) -> (N,T,F) rows. */
 int32_t regt_pack_x(const float* x, float* x_packed, int32_t num_nodes, int32_t num_features, int32_t periods,
                     regt_stream_t stream);
+
+/* ... rounding the snapshot to bf16 (nearest even) on the way: x_packed is (N, T, F) bf16, F % 8 == 0. */
+int32_t regt_pack_x_bf16(const float* x, void* x_packed, int32_t num_nodes, int32_t num_features, int32_t periods,
+                         regt_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense contraction -- torch.nn.Linear / PyG Linear call sites:
@@ -193,6 +203,13 @@ int32_t regt_forward_packed(const regt_dims* dims, const regt_graph* graph, cons
                             const float* x_packed, int32_t x_rows, float* pred, float* hidden,
                             void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* The same for a caller that packs (regt_pack_x_bf16) and exchanges its rows as bf16 -- half the bytes on the xGMI links and
+ * no conversion pass; needs REGT_GEMM_MODE=bf16 and a shape the fused forward covers (C = 256, F = 64, node-disjoint
+ * regions, merged operator), otherwise an error is returned.  regt_backward must then get the same buffer as x_packed. */
+int32_t regt_forward_packed_bf16(const regt_dims* dims, const regt_graph* graph, const regt_params* params,
+                                 const void* x_packed_bf16, int32_t x_rows, float* pred, float* hidden,
+                                 void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
 /* Gradients of all parameters given dL/dpred (N,O) and optionally dL/dhidden (N,C) (may be NULL).
  * Must follow regt_forward on the same workspace; `hidden` is that forward's hidden output;
  * x_packed is NULL after regt_forward, or the buffer given to regt_forward_packed. */
@@ -266,6 +283,12 @@ int32_t regt_gat_backward(const int32_t* rowptr, const int32_t* col, const int32
  * accumulation -- fp32-level rounding error (dropped terms <= 3 * 2^-24 of a product), ~2x the matrix-pipe rate.
  * Also selectable with REGT_GEMM_MODE=bf16x3 before the first call.  Returns the previous mode. */
 int32_t regt_set_gemm_mode(int32_t mode);
+
+/* Developer switches (A/B timing and the bit-for-bit comparisons of tests/test_gpu_fused.py); returns the previous value, -1 for
+ * an unknown name.  "xbf" (default 1): under REGT_GEMM_MODE=bf16, bf16 rows of x / A_hat x / L~ x and the fused forward kernel
+ * where the shape allows; 0 = the three-launch forward on fp32 rows.  "spmm_rows" (default 1): the row-block aggregation
+ * kernel (CSR entries of a workgroup's rows held in LDS); 0 = the column-panel kernels. */
+int32_t regt_set_option(const char* name, int32_t value);
 
 /* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures).  collect() waits for the recorded events and writes "name count total_ms"

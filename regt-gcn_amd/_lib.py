@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REGT_LIB_DIR: a developer build of the same library in another directory (build.py honours the same variable), e.g. the
 # workgroup-trace build of tools/wg_trace.py; never a different implementation
 LIB_PATH = os.path.join(os.environ.get("REGT_LIB_DIR") or os.path.join(HERE, "lib"), "libregtgcn_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -63,6 +63,7 @@ class Cell0Grads(C.Structure):
 SIGNATURES = {
     "regt_abi_version": (C.c_int32, []),
     "regt_set_gemm_mode": (C.c_int32, [C.c_int32]),
+    "regt_set_option": (C.c_int32, [C.c_char_p, C.c_int32]),
     "regt_cell_forward": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_cell_backward": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_last_error": (C.c_char_p, []),
@@ -74,6 +75,10 @@ SIGNATURES = {
     "regt_spmm_csr": (C.c_int32, [vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
     "regt_spmm_dual": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, vp]),
     "regt_pack_x": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_pack_x_bf16": (C.c_int32, [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_spmm_dual_bf16": (C.c_int32, [vp, vp, vp, vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "regt_forward_packed_bf16": (C.c_int32, [C.POINTER(Dims), C.POINTER(Graph), C.POINTER(Params), vp, C.c_int32, vp, vp, vp,
+                                             C.c_size_t, vp]),
     "regt_linear": (C.c_int32, [vp, C.c_int64, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32, vp, C.c_int32,
                                 C.c_float, vp, C.c_int64, vp]),
     "regt_wgrad_slab_floats": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

@@ -158,6 +158,17 @@ int q_format(const void* ws) {
     auto it = g_qfmt.find(ws);
     return it == g_qfmt.end() ? 0 : it->second;
 }
+// ... and, where the fused forward kernel applies (fused.hip: C = 256, F = 64, node-disjoint regions), x, A_hat x and L~ x as
+// well: the snapshot is rounded once while it is packed, the aggregation reads and writes bf16 rows (cfg-5).
+// REGT_XBF=0 keeps them fp32 and the three-launch forward (A/B timing; tests/test_gpu_fused.py compares the two bit for bit).
+int g_opt_xbf = -1;
+bool xbf_wanted() {
+    if (g_opt_xbf < 0) { const char* e = getenv("REGT_XBF"); g_opt_xbf = e ? atoi(e) : 1; }
+    return g_opt_xbf != 0;
+}
+// workspace formats remembered between forward and backward (note_q_format): bit 0 = bf16 intermediates, bit 1 = bf16 rows of
+// x / A_hat x / L~ x, bit 2 = the packed input was the CALLER's bf16 buffer (else the rounded copy lives in the workspace)
+enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4 };
 inline const float* byte_off(const float* p, long bytes) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + bytes); }
 
 // bf16 mode with bf16-stored activations: the GEMM weights get per-step bf16 copies in MFMA fragment order (SEG_B_FRAG: every
@@ -168,6 +179,12 @@ bool weights_frag(const regt_dims& d) {
     const long reg_slabs = (long)(std::min<long>(d.R, 128 / d.T + 2) + 1) * (d.F / 32);
     return bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced() && !fp32_core_wide() &&
            reg_slabs <= 64 && (2L * d.C + d.F) / 32 <= 64;
+}
+bool xbf_ok(const regt_dims& d, const regt_graph& g, bool h_ext, int x_rows, bool packed_fp32) {
+    return xbf_wanted() && weights_frag(d) && d.regional && d.R > 1 && !g.overlap && !h_ext && g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l &&
+           g.chunk_tab && g.chunk_region && g.n_chunks > 0 &&
+           fused_forward_ok(d.C, d.F) && ((long)d.T * d.F) % 64 == 0 && (!packed_fp32 || x_rows <= 2 * d.N) &&
+           (long)(x_rows > d.N ? x_rows : d.N) * d.T * d.F * 2 < (1L << 32) - 4096;
 }
 struct WbPtrs { const float *U[3], *UT[3], *Gzr, *Gh, *A0, *Aall; long ar_stride; };
 WbPtrs wb_ptrs(const float* Wb, long C, long F, long R) {
@@ -384,7 +401,7 @@ int head_forward(const regt_dims& d, const regt_params& p, const float* hidden, 
 // regional / Cheb embedding stage is skipped and only A_hat x is aggregated (graph = the N rows of A_hat).
 int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const float* x, const float* xp_ext,
                  int x_rows, float* pred, float* hidden, const Layout& L, hipStream_t st, bool skip_pack = false,
-                 const float* h_ext = nullptr) {
+                 const float* h_ext = nullptr, int fmt = 0) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const float* H = h_ext ? h_ext : L.h;
@@ -394,6 +411,45 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         PROF("compose_fwd", st);
         TRY(launch_softmax_small(p.attention, L.probs, T, st));
         TRY(compose_forward(d, g, p, L, st));
+    }
+    if (fmt & FMT_XBF) {
+        // bf16 rows of x, A_hat x, L~ x + the fused cell kernel (fused.hip)
+        const void* Xb = (fmt & FMT_XCALLER) ? static_cast<const void*>(xp_ext) : static_cast<const void*>(L.Xp);
+        if (!(fmt & FMT_XCALLER) && !skip_pack) {
+            PROF("pack_x", st);
+            if (xp_ext) TRY(launch_cvt_rows_bf16(xp_ext, L.Xp, (long)x_rows * T * F, st));
+            else TRY(launch_pack_x_bf16(x, L.Xp, N, F, T, st));
+        }
+        {
+            PROF("spmm", st);
+            TRY(launch_spmm_dual_bf16(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xb, L.AX, L.LX, N, xp_ext ? x_rows : N, T * F, st));
+        }
+        const WbPtrs wbf = wb_ptrs(L.Wb, C, F, R);
+        {
+            CvtBatch cb{};
+            cb.n = 0;
+            for (int k = 0; k < 3; ++k) cb.t[cb.n++] = CvtTask{p.gate_w[k] + C, 2L * C, C, C, const_cast<float*>(wbf.U[k])};
+            cb.t[cb.n++] = CvtTask{L.Gzr, F, 2 * C, F, const_cast<float*>(wbf.Gzr)};
+            cb.t[cb.n++] = CvtTask{L.Gh, F, C, F, const_cast<float*>(wbf.Gh)};
+            cb.t[cb.n++] = CvtTask{L.A0, F, C, F, const_cast<float*>(wbf.A0)};
+            cb.t[cb.n++] = CvtTask{L.Aall, F, R * C, F, const_cast<float*>(wbf.Aall)};
+            PROF("weights_bf16", st);
+            TRY(launch_cvt_bf16_frag(cb, st));
+        }
+        {
+            FusedFwdArgs a{};
+            a.X = Xb; a.LX = L.LX; a.AX = L.AX;
+            a.A0f = wbf.A0; a.Aallf = wbf.Aall; a.ar_stride = wbf.ar_stride;
+            a.Uzf = wbf.U[0]; a.Urf = wbf.U[1]; a.Uhf = wbf.U[2]; a.Gzrf = wbf.Gzr; a.Ghf = wbf.Gh;
+            a.bprime = L.bprime; a.czr = L.czr; a.ch = L.ch; a.probs = L.probs;
+            a.node_region = R > 1 ? g.node_region : nullptr;
+            a.h = L.h; a.ZR = L.ZR; a.q = L.q; a.Ht = L.Ht; a.OH = hidden;
+            a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = 1;
+            PROF("fused_forward", st);
+            TRY(launch_zero_f32(hidden, (long)N * C, st));
+            TRY(launch_fused_forward(a, C, F, st));
+        }
+        return head_forward(d, p, hidden, L.y1, pred, st);
     }
     // 1. pack the snapshot and aggregate: [A_hat; L~] x  (one stacked SpMM over 2N rows, width T*F)
     const float* Xp = xp_ext ? xp_ext : L.Xp;
@@ -408,7 +464,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         else if (g.overlap)
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, (1 + R) * N, xp_ext ? x_rows : N, T * F, 1 + R, st));
         else if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
-            TRY(launch_spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, T * F, st));
+            TRY(launch_spmm_dual_x(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, xp_ext ? x_rows : N, T * F, st));
         else
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, 2, st));
     }
@@ -594,10 +650,11 @@ int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr
 // written to dh_ext and the embedding-stage gradients (A0 / A_r / Cheb weights) are skipped.
 int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, const regt_grads& gr,
                   const float* dpred, const float* dhidden, const float* hidden, const float* xp_ext, const Layout& L,
-                  hipStream_t st, int qbf, const float* h_ext = nullptr, float* dh_ext = nullptr) {
+                  hipStream_t st, int fmt, const float* h_ext = nullptr, float* dh_ext = nullptr) {
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
-    const float* Xp = xp_ext ? xp_ext : L.Xp;
+    const int qbf = fmt & FMT_QBF, xbf = (fmt & FMT_XBF) ? 1 : 0;     // xbf: x, A_hat x, L~ x hold bf16 rows (the forward's format)
+    const float* Xp = (xp_ext && (!xbf || (fmt & FMT_XCALLER))) ? xp_ext : L.Xp;
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
     const int ibf = bf16_intermediates(d) ? 1 : 0;      // dhp, dzp|drp stored as bf16 (and q, by the forward: checked by the caller)
@@ -664,7 +721,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     }
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
     TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
-    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st, ibf, 0));
+    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st, ibf, xbf));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
         a.p_bf16 = ibf; a.q_bf16 = abf;
@@ -682,7 +739,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(rq.push(r));
         }
     }
-    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st, ibf, 0));
+    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st, ibf, xbf));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
@@ -693,7 +750,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         REGT_CHECK_ARG(g.chunk_tab && g.chunk_region && g.n_chunks > 0, "backward: region chunk table missing");
         WgradArgs a{L.dh, C, C, Xp, F, 2 * F, 0, M, 0, g.chunk_tab, g.n_chunks, nullptr, 1};
         a.Q2 = L.LX; a.ldq2 = F; a.nin_split = F;
-        a.p_bf16 = abf;
+        a.p_bf16 = abf; a.q_bf16 = xbf;
         TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_A0_Ar", st);
@@ -808,6 +865,14 @@ int32_t regt_set_gemm_mode(int32_t mode) {
 }
 const char* regt_last_error(void) { return g_err; }
 
+int32_t regt_set_option(const char* name, int32_t value) {
+    REGT_CHECK_ARG(name != nullptr, "regt_set_option: name is NULL");
+    if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
+    if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
+    set_error("regt_set_option: unknown option '%s'", name);
+    return -1;
+}
+
 size_t regt_graph_workspace_bytes(int64_t E, int32_t N) { return graph_workspace_bytes((long)E, N); }
 
 int32_t regt_gcn_csr(const int64_t* ei, const float* w, int64_t E, int32_t N, int32_t* rowptr, int32_t* col, float* val,
@@ -893,7 +958,7 @@ size_t regt_workspace_bytes(const regt_dims* dims, int32_t n_chunks, int32_t ove
 
 static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
                               const float* xp_ext, int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes,
-                              regt_stream_t st) {
+                              regt_stream_t st, bool xp_is_bf16 = false) {
     TRY(check_dims(dims));
     REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && (graph->node_region || graph->overlap), "regt_forward: graph incomplete");
     TRY(check_ptrs(params, *dims));
@@ -904,19 +969,28 @@ static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, co
     Layout L = make_layout(*dims, graph->n_chunks, graph->overlap, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_forward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     hipStream_t hs = (hipStream_t)st;
-    note_q_format(ws, bf16_intermediates(*dims) ? 1 : 0);
+    int fmt = bf16_intermediates(*dims) ? FMT_QBF : 0;
+    if (fmt && xbf_ok(*dims, *graph, false, xp_ext ? x_rows : dims->N, xp_ext && !xp_is_bf16)) fmt |= FMT_XBF | (xp_is_bf16 ? FMT_XCALLER : 0);
+    REGT_CHECK_ARG(!xp_is_bf16 || (fmt & FMT_XBF), "regt_forward_packed_bf16: bf16 input rows need REGT_GEMM_MODE=bf16 and a shape the fused "
+                   "forward covers (C = 256, F = 64, node-disjoint regions, merged operator)");
+    note_q_format(ws, fmt);
     if (!graphs_wanted((long)dims->N * dims->T))
-        return forward_impl(*dims, *graph, *params, x, xp_ext, x_rows, pred, hidden, L, hs);
+        return forward_impl(*dims, *graph, *params, x, xp_ext, x_rows, pred, hidden, L, hs, false, nullptr, fmt);
     // the snapshot changes every step: pack it with a plain launch, replay everything behind it
-    if (!xp_ext) TRY(launch_pack_x(x, L.Xp, dims->N, dims->F, dims->T, hs));
+    if (!xp_ext) {
+        if (fmt & FMT_XBF) TRY(launch_pack_x_bf16(x, L.Xp, dims->N, dims->F, dims->T, hs));
+        else TRY(launch_pack_x(x, L.Xp, dims->N, dims->F, dims->T, hs));
+    } else if ((fmt & FMT_XBF) && !(fmt & FMT_XCALLER)) {
+        TRY(launch_cvt_rows_bf16(xp_ext, L.Xp, (long)x_rows * dims->T * dims->F, hs));
+    }
     unsigned long long key = hash_bytes(dims, sizeof(*dims), 0xcbf29ce484222325ull);
     key = hash_bytes(graph, sizeof(*graph), key);
     key = hash_bytes(params, sizeof(*params), key);
-    const void* ptrs[5] = {xp_ext, pred, hidden, ws, (const void*)(long)x_rows};
+    const void* ptrs[6] = {xp_ext, pred, hidden, ws, (const void*)(long)x_rows, (const void*)(long)fmt};
     key = hash_bytes(ptrs, sizeof(ptrs), key);
     const regt_dims dd = *dims; const regt_graph gg = *graph; const regt_params pp = *params;
     return run_maybe_graphed(g_fwd_graphs, key, hs, [=](hipStream_t s) {
-        return forward_impl(dd, gg, pp, x, xp_ext, x_rows, pred, hidden, L, s, /*skip_pack=*/true);
+        return forward_impl(dd, gg, pp, x, xp_ext, x_rows, pred, hidden, L, s, /*skip_pack=*/true, nullptr, fmt);
     });
 }
 
@@ -930,6 +1004,23 @@ int32_t regt_forward_packed(const regt_dims* dims, const regt_graph* graph, cons
                             int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
     REGT_CHECK_ARG(x_packed != nullptr, "regt_forward_packed: x_packed is NULL");
     return forward_common(dims, graph, params, nullptr, x_packed, x_rows, pred, hidden, ws, ws_bytes, st);
+}
+
+int32_t regt_forward_packed_bf16(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const void* x_packed_bf16,
+                                 int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
+    REGT_CHECK_ARG(x_packed_bf16 != nullptr, "regt_forward_packed_bf16: x_packed is NULL");
+    return forward_common(dims, graph, params, nullptr, static_cast<const float*>(x_packed_bf16), x_rows, pred, hidden, ws, ws_bytes, st, true);
+}
+
+int32_t regt_pack_x_bf16(const float* x, void* xp, int32_t N, int32_t F, int32_t T, regt_stream_t st) {
+    REGT_CHECK_ARG(x && xp && N > 0 && F > 0 && T > 0, "regt_pack_x_bf16: bad argument");
+    return launch_pack_x_bf16(x, xp, N, F, T, (hipStream_t)st);
+}
+
+int32_t regt_spmm_dual_bf16(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const void* X,
+                            void* YA, void* YL, int32_t N, int32_t x_rows, int32_t width, regt_stream_t st) {
+    REGT_CHECK_ARG(rowptr && col && val_a && val_l && X && YA && YL && x_rows >= N, "regt_spmm_dual_bf16: NULL pointer / x_rows < N");
+    return launch_spmm_dual_bf16(rowptr, col, val_a, val_l, X, YA, YL, N, x_rows, width, (hipStream_t)st);
 }
 
 int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const regt_grads* grads,
@@ -950,15 +1041,16 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     hipStream_t hs = (hipStream_t)st;
     const int qbf = q_format(ws);
-    REGT_CHECK_ARG(qbf == (bf16_intermediates(*dims) ? 1 : 0),
+    REGT_CHECK_ARG((qbf & FMT_QBF) == (bf16_intermediates(*dims) ? 1 : 0),
                    "regt_backward: the GEMM arithmetic changed since the forward on this workspace (regt_set_gemm_mode between forward and backward)");
+    REGT_CHECK_ARG(!(qbf & FMT_XCALLER) || x_packed, "regt_backward: the forward ran on the caller's bf16 packed input; pass the same buffer as x_packed");
     if (!graphs_wanted((long)dims->N * dims->T))
         return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, hs, qbf);
     unsigned long long key = hash_bytes(dims, sizeof(*dims), 0x84222325cbf29ce4ull);
     key = hash_bytes(graph, sizeof(*graph), key);
     key = hash_bytes(params, sizeof(*params), key);
     key = hash_bytes(grads, sizeof(*grads), key);
-    const void* ptrs[5] = {dpred, dhidden, hidden, x_packed, ws};
+    const void* ptrs[6] = {dpred, dhidden, hidden, x_packed, ws, (const void*)(long)qbf};
     key = hash_bytes(ptrs, sizeof(ptrs), key);
     const regt_dims dd = *dims; const regt_graph gg = *graph; const regt_params pp = *params; const regt_grads gr = *grads;
     return run_maybe_graphed(g_bwd_graphs, key, hs, [=](hipStream_t s) {
@@ -1007,7 +1099,7 @@ int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const
     Layout L = make_layout(*dims, 0, 0, (char*)ws);
     REGT_CHECK_ARG(ws_bytes >= L.bytes, "regt_cell_backward: workspace %zu < required %zu bytes", ws_bytes, L.bytes);
     const int qbf = q_format(ws);
-    REGT_CHECK_ARG(qbf == (bf16_intermediates(*dims) ? 1 : 0),
+    REGT_CHECK_ARG((qbf & FMT_QBF) == (bf16_intermediates(*dims) ? 1 : 0),
                    "regt_cell_backward: the GEMM arithmetic changed since the forward on this workspace");
     return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, nullptr, L, (hipStream_t)st, qbf, h_in, dh_in);
 }

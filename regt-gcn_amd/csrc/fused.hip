@@ -1,0 +1,349 @@
+// Fused forward of the RegT-GCN cell for the bf16 arithmetic (REGT_GEMM_MODE=bf16, BASELINE configs[4]): regional embedding ->
+// update / reset gates -> candidate state -> GRU blend -> attention-weighted sum over the periods, ONE kernel per 64-row tile.
+//
+// Replaces, per period and node (rows m = node * T + t), the op sites
+//     h  = leaky_relu(linear(concat_r ChebConv_r(x)))                 models/RegionalTemporalGCN.py:136-143
+//     Z  = sigmoid(linear_z([conv_z(x) | h])),  R = sigmoid(linear_r([conv_r(x) | h]))      models/utils.py:168-178
+//     H~ = tanh(linear_h([conv_h(x) | h * R])),  H' = Z h + (1 - Z) H~                        models/utils.py:180-188
+//     H_accum += softmax(attention)[t] H'                                                    models/RegionalTemporalGCN.py:146
+// in the composed-weight form of DESIGN.md section 3.  The three-launch version (gemm_regional, gemm_gates, gemm_candidate)
+// writes h, [Z|R], q = h R and H~ for the backward pass AND reads h (twice), Z and q back: 8.5 GB per step at the cfg-5
+// shard.  Here a workgroup keeps its 64 rows of h and q in LDS as matrix-core A operands (bf16, the layout of SplitCore's
+// stage planes) and Z in registers, so every activation is written once and nothing is read back: 4.4 GB.
+//
+// Shape of the work: 256 threads = 4 waves; the tile's outputs are produced in 128-column tiles, wave w owns columns
+// 32 w .. 32 w + 31 of the tile and all 64 rows (two 32 x 32 accumulators).  The B operands are the per-step bf16 copies of
+// the weights in MFMA fragment order (launch_cvt_bf16_frag): a wave loads its fragments of a whole K loop up front, straight
+// into registers.  The K = F operands (x, L~ x, A_hat x: bf16 rows written by the aggregation kernel) are loaded as A
+// fragments directly from global memory (A_hat x once per tile, kept in registers for all six K loops that use it).
+// Epilogues go through a 16-row fp32 image in LDS (4 rounds per 64 x 128 tile): a thread then owns (row, 8 consecutive
+// columns) = 16 bytes of every bf16 array -- the same thread owns the same (row, columns) in the Z and in the candidate
+// epilogue, which is what lets Z stay in registers.  LDS: 32 KB h planes + 32 KB q planes + 8.4 KB image + tables = 74 KB,
+// two workgroups per CU: one's epilogue VALU and stores overlap the other's matrix work.
+//
+// Arithmetic, rounding points and summation orders are exactly those of the three-launch path (bf16 MFMA operands, fp32
+// accumulate over k in ascending 16-k blocks, fp32 gate math, one rounding per stored element, per-node partial sums over a
+// 64-row block in row order): with the same bf16 inputs both paths give bit-identical results (tests/test_gpu_fused.py).
+#include "kernels.h"
+#include "gemm_split.h"
+
+namespace regt {
+
+namespace {
+
+struct FRow { int node; float p; };      // node index relative to the tile's first node (-1: row past the end), attention probability
+
+__device__ __forceinline__ float f_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float f_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float4 f_widen4(unsigned lo, unsigned hi) {
+    return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
+}
+struct V8 { float v[8]; };
+__device__ __forceinline__ V8 f_widen8(u32x4_t r) {
+    V8 o;
+    o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
+    o.v[2] = __uint_as_float(r.y << 16); o.v[3] = __uint_as_float(r.y & 0xffff0000u);
+    o.v[4] = __uint_as_float(r.z << 16); o.v[5] = __uint_as_float(r.z & 0xffff0000u);
+    o.v[6] = __uint_as_float(r.w << 16); o.v[7] = __uint_as_float(r.w & 0xffff0000u);
+    return o;
+}
+__device__ __forceinline__ u32x4_t f_pack8(const V8& a) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    u32x4_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2_t p = {a.v[2 * i], a.v[2 * i + 1]};
+        r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2_t));
+    }
+    return r;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f_rsrc(const void* p, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes > 0x7ffffff0L ? 0x7ffffff0 : (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 f_ldfrag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+constexpr int FT_ROWS = 64;              // rows of a tile
+constexpr int FT_IMG_LD = 132;           // floats per image row (128 columns + 4: conflict-free 16-byte reads)
+constexpr int FT_IMG_ROWS = 16;
+
+}  // namespace
+
+template <int C, int F>
+struct FusedFwdLds {
+    static constexpr int PLANE_B = FT_ROWS * 32;                 // one 16-k block of 64 rows
+    static constexpr int OPER_B = (C / 16) * PLANE_B;            // h (or q) of the tile as an A operand
+    static constexpr int IMG_OFF = 2 * OPER_B;
+    static constexpr int TAB_OFF = IMG_OFF + FT_IMG_ROWS * FT_IMG_LD * 4;
+    static constexpr int BYTES = TAB_OFF + FT_ROWS * (int)sizeof(FRow) + FT_ROWS * 4 + (FT_ROWS + 4) * 4;
+};
+
+template <int C, int F>
+__global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
+    static_assert(C % 128 == 0 && F % 16 == 0, "tile shapes");
+    using L = FusedFwdLds<C, F>;
+    constexpr int KBC = C / 16, KBF = F / 16, NT = C / 128;
+    extern __shared__ __attribute__((aligned(16))) char flds[];
+    char* Hp = flds;
+    char* Qp = flds + L::OPER_B;
+    float* img = reinterpret_cast<float*>(flds + L::IMG_OFF);
+    FRow* rowtab = reinterpret_cast<FRow*>(flds + L::TAB_OFF);
+    int* rreg = reinterpret_cast<int*>(rowtab + FT_ROWS);
+    int* ulist = rreg + FT_ROWS;                                 // [0] = number of distinct regions, then the regions
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: fragment addresses go into scalar offsets
+    const long m0 = (long)blockIdx.x * FT_ROWS;
+    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+    const long node0 = m0 / a.T;
+    if (tid < FT_ROWS) {
+        const long m = m0 + tid;
+        const long node = m / a.T;
+        const int t = (int)(m - node * a.T);
+        const bool ok = tid < nvalid;
+        rowtab[tid] = FRow{ok ? (int)(node - node0) : -1, ok ? a.probs[t] : 0.f};
+        rreg[tid] = ok ? (a.node_region ? a.node_region[node] : 0) : -1;
+    }
+    __syncthreads();
+    if (tid == 0) {        // distinct regions of the tile's rows, in order of first appearance (usually one)
+        int n = 0;
+        for (int r = 0; r < nvalid; ++r) {
+            const int g = rreg[r];
+            bool seen = false;
+            for (int i = 0; i < n; ++i) seen = seen || ulist[1 + i] == g;
+            if (!seen) ulist[1 + n++] = g;
+        }
+        ulist[0] = n;
+    }
+    __syncthreads();
+    const int nuniq = __builtin_amdgcn_readfirstlane(ulist[0]);
+
+    // ---- descriptors: the tile's rows of every activation array (rows past the end are out of range: loads return 0, stores are dropped)
+    const __amdgpu_buffer_rsrc_t sX = f_rsrc(reinterpret_cast<const char*>(a.X) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
+    // A-fragment offsets of the K = F operands: lane (lr, lh) holds k = 8 lh .. 8 lh + 7 of row 32 mi + lr of a 16-k block
+    const int afo = lr * F * 2 + lh * 16;
+    bf16x8 axf[2][KBF];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) axf[mi][kb] = f_ldfrag(sAX, afo + mi * 32 * F * 2, kb * 32);
+
+    // epilogue thread geometry: round rnd = rows 16 rnd .. 16 rnd + 15 of the tile; thread = (row tid >> 4, columns 8 (tid & 15) ..+7)
+    const int er = tid >> 4, ec = 8 * (tid & 15);
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {          // accumulators of round rnd -> image (between two barriers)
+        const int mi = rnd >> 1, rd = rnd & 1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
+            img[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + 32 * w + lr] = mi ? acc[1][reg] : acc[0][reg];
+        }
+        __syncthreads();
+    };
+    auto img8 = [&]() {
+        const float4* p = reinterpret_cast<const float4*>(img + er * FT_IMG_LD + ec);
+        const float4 lo = p[0], hi = p[1];
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    auto bias8 = [&](const float* b) {
+        const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    // the 16 bytes of (row, columns c .. c + 7) inside an operand's planes
+    auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
+    // acc += P (planes, K = C) x W^T (fragments of column block nb), then the A_hat x part with G (column block nbg)
+    auto kloop = [&](f32x16 (&acc)[2], const char* P, const void* Wf, int nb, const void* Gf, int nbg) {
+        const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2), sG = f_rsrc(Gf, (long)0x7ffffff0);
+        bf16x8 bw[KBC], bg[KBF];
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb) bw[kb] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) bg[kb] = f_ldfrag(sG, lane * 16, (nbg * KBF + kb) * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(P + kb * L::PLANE_B + sp_off(lr, lh));
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(P + kb * L::PLANE_B + sp_off(32 + lr, lh));
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bw[kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[kb], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axf[0][kb], bg[kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axf[1][kb], bg[kb], acc[1], 0, 0, 0);
+        }
+    };
+    auto zero = [&](f32x16 (&acc)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    };
+
+    // ---- phase 0: regional embedding h = act(x A0^T + (L~ x) A_region^T + b') -> global + h planes --------------------------
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        const int nb = 4 * j + w;
+        f32x16 acc[2];
+        zero(acc);
+        {
+            const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
+            bf16x8 b[KBF], x[2][KBF];
+#pragma unroll
+            for (int kb = 0; kb < KBF; ++kb) {
+                b[kb] = f_ldfrag(sA0, lane * 16, (nb * KBF + kb) * 1024);
+                x[0][kb] = f_ldfrag(sX, afo, kb * 32);
+                x[1][kb] = f_ldfrag(sX, afo + 32 * F * 2, kb * 32);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KBF; ++kb) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][kb], b[kb], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][kb], b[kb], acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll 1
+        for (int u = 0; u < nuniq; ++u) {       // one pass per distinct region of the tile: rows of other regions contribute zeros
+            const int rg = __builtin_amdgcn_readfirstlane(ulist[1 + u]);
+            const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg * a.ar_stride, (long)C * F * 2);
+            const int o0 = rreg[lr] == rg ? afo : 0x7ffffff0, o1 = rreg[32 + lr] == rg ? afo + 32 * F * 2 : 0x7ffffff0;
+            bf16x8 b[KBF], x[2][KBF];
+#pragma unroll
+            for (int kb = 0; kb < KBF; ++kb) {
+                b[kb] = f_ldfrag(sAr, lane * 16, (nb * KBF + kb) * 1024);
+                x[0][kb] = f_ldfrag(sLX, o0, kb * 32);
+                x[1][kb] = f_ldfrag(sLX, o1, kb * 32);
+            }
+#pragma unroll
+            for (int kb = 0; kb < KBF; ++kb) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][kb], b[kb], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][kb], b[kb], acc[1], 0, 0, 0);
+            }
+        }
+        const V8 b = bias8(a.bprime + 128 * j + ec);
+        const float ns = a.act_lrelu ? a.slope : 1.0f;
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            stage(acc, rnd);
+            const V8 v = img8();
+            V8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float s = v.v[i] + b.v[i]; o.v[i] = s > 0.f ? s : s * ns; }
+            const u32x4_t pk = f_pack8(o);
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            __builtin_amdgcn_raw_buffer_store_b128(pk, sh, (row * C + c) * 2, 0, 0);
+            *reinterpret_cast<u32x4_t*>(Hp + plane_off(row, c)) = pk;
+        }
+    }
+    __syncthreads();                                            // h planes complete
+
+    // ---- phase 1: reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R -> global + q planes ---------------------------
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        f32x16 acc[2];
+        zero(acc);
+        kloop(acc, Hp, a.Urf, 4 * j + w, a.Gzrf, C / 32 + 4 * j + w);
+        const V8 b = bias8(a.czr + C + 128 * j + ec);
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            stage(acc, rnd);
+            const V8 v = img8();
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            const V8 hv = f_widen8(*reinterpret_cast<const u32x4_t*>(Hp + plane_off(row, c)));
+            V8 g, qv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { g.v[i] = f_sigmoid(v.v[i] + b.v[i]); qv.v[i] = hv.v[i] * g.v[i]; }
+            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(g), sZR, (row * 2 * C + C + c) * 2, 0, 0);
+            const u32x4_t pq = f_pack8(qv);
+            __builtin_amdgcn_raw_buffer_store_b128(pq, sq, (row * C + c) * 2, 0, 0);
+            *reinterpret_cast<u32x4_t*>(Qp + plane_off(row, c)) = pq;
+        }
+    }
+    __syncthreads();                                            // q planes complete
+
+    // ---- phases 2 + 3 per column tile: update gate Z (kept in registers), candidate H~, blend, sum over the node's periods ---
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        u32x4_t zk[4];
+        {
+            f32x16 acc[2];
+            zero(acc);
+            kloop(acc, Hp, a.Uzf, 4 * j + w, a.Gzrf, 4 * j + w);
+            const V8 b = bias8(a.czr + 128 * j + ec);
+#pragma unroll
+            for (int rnd = 0; rnd < 4; ++rnd) {
+                stage(acc, rnd);
+                const V8 v = img8();
+                V8 g;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g.v[i] = f_sigmoid(v.v[i] + b.v[i]);
+                zk[rnd] = f_pack8(g);
+                __builtin_amdgcn_raw_buffer_store_b128(zk[rnd], sZR, ((16 * rnd + er) * 2 * C + 128 * j + ec) * 2, 0, 0);
+            }
+        }
+        f32x16 acc[2];
+        zero(acc);
+        kloop(acc, Qp, a.Uhf, 4 * j + w, a.Ghf, 4 * j + w);
+        const V8 b = bias8(a.ch + 128 * j + ec);
+        int cur = -1;                    // threads 0..127: running sum of column tid over the rows of node `cur`
+        float csum = 0.f;
+        float* oh = a.OH + node0 * C + 128 * j + tid;
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            stage(acc, rnd);
+            const V8 v = img8();
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            const V8 hv = f_widen8(*reinterpret_cast<const u32x4_t*>(Hp + plane_off(row, c)));
+            const V8 Zv = f_widen8(zk[rnd]);
+            const float pt = rowtab[row].p;
+            V8 ht, bl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ht.v[i] = f_tanh(v.v[i] + b.v[i]);
+                bl.v[i] = pt * (Zv.v[i] * hv.v[i] + (1.0f - Zv.v[i]) * ht.v[i]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(ht), sHt, (row * C + c) * 2, 0, 0);
+            float4* p = reinterpret_cast<float4*>(img + er * FT_IMG_LD + ec);
+            p[0] = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
+            p[1] = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
+            __syncthreads();
+            if (tid < 128) {
+#pragma unroll 4
+                for (int r = 0; r < FT_IMG_ROWS; ++r) {
+                    const int nd = rowtab[16 * rnd + r].node;
+                    if (nd != cur) {
+                        if (cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+                        cur = nd;
+                        csum = 0.f;
+                    }
+                    if (nd >= 0) csum += img[r * FT_IMG_LD + tid];
+                }
+            }
+        }
+        if (tid < 128 && cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+    }
+}
+
+int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st) {
+    REGT_CHECK_ARG(a.M > 0 && a.T > 0, "fused forward: empty problem");
+    REGT_CHECK_ARG(C == 256 && F == 64, "fused forward: built for C = 256, F = 64 (got C = %d, F = %d)", C, F);
+    const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
+    REGT_CHECK_ARG(tiles < (1L << 31), "fused forward: too many tiles");
+    using L = FusedFwdLds<256, 64>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<256, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+bool fused_forward_ok(int C, int F) { return C == 256 && F == 64; }
+
+}  // namespace regt

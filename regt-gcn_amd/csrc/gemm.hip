@@ -1974,12 +1974,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
     // two-part right-hand side [Q | Q2] (fp32, columns >= nin_split come from Q2; the host admits it for Nin <= 128): a wave's
     // lanes straddle the split, so every slot is requested from both descriptors with complementary out-of-range masks
     // (an out-of-range lane returns 0 without touching memory) and the two results are OR-ed
-    const bool has_q2 = !QBF && a.Q2 != nullptr;
-    const bool in_q2 = has_q2 && j0 + 4 * c4 >= a.nin_split;
-    const bool okq = (QBF ? j0 + 8 * c8 < a.Nin : j0 + 4 * c4 < a.Nin) && !in_q2;
-    const bool okq2 = in_q2 && j0 + 4 * c4 < a.Nin;
-    const int ldq2 = (int)a.ldq2, cq2 = j0 + 4 * c4 - a.nin_split;
-    const __amdgpu_buffer_rsrc_t sq2 = Core::make_srd(has_q2 ? a.Q2 + r0 * a.ldq2 : a.Q);
+    // (bf16-stored Q: the same with the thread's 8-column chunk; nin_split % 8 == 0, host-checked)
+    const bool has_q2 = a.Q2 != nullptr;
+    const int qcol = QBF ? j0 + 8 * c8 : j0 + 4 * c4;        // first of the thread's columns of [Q | Q2]
+    const bool in_q2 = has_q2 && qcol >= a.nin_split;
+    const bool okq = qcol < a.Nin && !in_q2;
+    const bool okq2 = in_q2 && qcol < a.Nin;
+    const int ldq2 = (int)a.ldq2, cq2 = qcol - a.nin_split;
+    const __amdgpu_buffer_rsrc_t sq2 = Core::make_srd(has_q2 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.Q2) + (QBF ? 2 : 4) * (r0 * a.ldq2))
+                                                             : a.Q);
     const float qfloor = a.q_relu ? 0.f : -__builtin_inff();
 
     // fp32 operand: slot s of a thread: half h = s & 1, row 16 h + (tid >> 5) + 8 (s >> 1) of the 32-row slab (registers
@@ -1991,7 +1994,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
         }
         if (QBF) {
             const int m = k0 + 16 * h + (tid >> 4);
-            rq[h] = Core::srd_load(sq, live && m < nrows && okq ? 2u * (unsigned)(m * ldq + 8 * c8) : Core::SRD_OOB);
+            float4 q = Core::srd_load(sq, live && m < nrows && okq ? 2u * (unsigned)(m * ldq + 8 * c8) : Core::SRD_OOB);
+            if (has_q2) {
+                const float4 q2 = Core::srd_load(sq2, live && m < nrows && okq2 ? 2u * (unsigned)(m * ldq2 + cq2) : Core::SRD_OOB);
+                q.x = __uint_as_float(__float_as_uint(q.x) | __float_as_uint(q2.x));
+                q.y = __uint_as_float(__float_as_uint(q.y) | __float_as_uint(q2.y));
+                q.z = __uint_as_float(__float_as_uint(q.z) | __float_as_uint(q2.z));
+                q.w = __uint_as_float(__float_as_uint(q.w) | __float_as_uint(q2.w));
+            }
+            rq[h] = q;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -2000,7 +2011,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
             if (!PBF) rp[h + 2 * j] = Core::srd_load(sp, ok && okp ? 4u * (unsigned)(m * ldp + 4 * c4) : Core::SRD_OOB);
             if (!QBF) {
                 float4 q = Core::srd_load(sq, ok && okq ? 4u * (unsigned)(m * ldq + 4 * c4) : Core::SRD_OOB);
-                if (has_q2) {
+                if (has_q2 && !QBF) {
                     const float4 q2 = Core::srd_load(sq2, ok && okq2 ? 4u * (unsigned)(m * ldq2 + cq2) : Core::SRD_OOB);
                     q.x = __uint_as_float(__float_as_uint(q.x) | __float_as_uint(q2.x));
                     q.y = __uint_as_float(__float_as_uint(q.y) | __float_as_uint(q2.y));
@@ -2288,7 +2299,8 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.Nout > 0 && a.Nin > 0 && a.nchunks > 0, "wgrad: empty problem");
     // a two-part right-hand side runs on the skinny fp32 kernel, except under the bf16 arithmetic with Nin <= 128 (one
     // column tile of the bf16-pipe kernel: at F = 64 the fused dA0 / dA_r gradient is fp32-MFMA-bound on the skinny kernel)
-    const bool q2_split = a.Q2 && gemm_mode() == 2 && a.Nin > 32 && a.Nin <= 128 && !a.q_bf16 && !a.q_relu && a.nin_split % 4 == 0 && !fp32_core_wide();
+    const bool q2_split = a.Q2 && gemm_mode() == 2 && a.Nin > 32 && a.Nin <= 128 && !a.q_relu && a.nin_split % (a.q_bf16 ? 8 : 4) == 0 && !fp32_core_wide() &&
+                          (!a.q_bf16 || a.ldq2 % 8 == 0);
     const bool wide = a.Nin > 32 && (!a.Q2 || q2_split);
     const int bnw = wide ? 128 : 32;
     long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;

@@ -202,6 +202,31 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
 
 int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
                      float* YL, int nnodes, int W, hipStream_t st);   // YA = A x, YL = L x from one merged CSR (two weights/entry)
+// the same with X holding x_rows >= nnodes rows (region shard: own rows, then halo rows)
+int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
+                       float* YL, int nnodes, int x_rows, int W, hipStream_t st);
+// bf16 rows in (X: x_rows x W bf16) and out (YA, YL: nnodes x W bf16), fp32 accumulation, one rounding at the end; W % 64 == 0
+int launch_spmm_dual_bf16(const int* rowptr, const int* col, const float* val_a, const float* val_l, const void* X, void* YA, void* YL,
+                          int nnodes, int x_rows, int W, hipStream_t st);
+
+int spmm_rows_option(int value);   // runtime A/B switch of the row-block aggregation kernel (regt_set_option "spmm_rows")
+int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_t st);        // (N,F,T) fp32 -> (N,T,F) bf16, F % 8 == 0
+int launch_cvt_rows_bf16(const float* src, void* dst, long n, hipStream_t st);                // n % 8 == 0 elements fp32 -> bf16
+
+// ---- fused forward of the cell for the bf16 arithmetic (fused.hip) ----------------------------------------------------------
+struct FusedFwdArgs {
+    const void *X, *LX, *AX;                  // bf16 rows (M x F): packed input, L~ x, A_hat x (rows node * T + t)
+    const void *A0f, *Aallf; long ar_stride;  // composed (C x F) weights in MFMA fragment order (launch_cvt_bf16_frag), one block per region
+    const void *Uzf, *Urf, *Uhf;              // the h-halves of linear_z / _r / _h (C x C), fragment order
+    const void *Gzrf, *Ghf;                   // composed [Gz; Gr] (2C x F) and Gh (C x F), fragment order
+    const float *bprime, *czr, *ch, *probs;   // composed biases (C, 2C, C), softmax(attention) (T)
+    const int* node_region;                   // (nodes) or nullptr (one region)
+    void *h, *ZR, *q, *Ht;                    // bf16 outputs: (M x C), (M x 2C) = [Z | R], (M x C), (M x C)
+    float* OH;                                // (nodes x C) fp32, zero-initialised: the attention-weighted hidden state
+    long M; int T; float slope; int act_lrelu;
+};
+int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st);
+bool fused_forward_ok(int C, int F);
 
 // ---- cell backward head / small element-wise kernels -------------------------------------------
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)

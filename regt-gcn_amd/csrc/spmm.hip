@@ -38,6 +38,54 @@ int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st
     return REGT_OK;
 }
 
+// bf16 rows for the bf16 arithmetic (REGT_GEMM_MODE=bf16): x, A_hat x and L~ x only ever feed matrix-core operands there, so
+// the snapshot is rounded once while it is packed (round to nearest even) and the aggregation reads and writes bf16 rows.
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+    const pk_f32x2 p = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(p, pk_bf16x2));
+}
+// (N, F, T) fp32 -> (N, T, F) bf16; F % 8 == 0: a thread writes the 16 bytes of 8 consecutive features of one (node, period)
+__global__ void pack_x_bf16_kernel(const float* __restrict__ x, uint4* __restrict__ xp, long N, int F, int T) {
+    const int f8 = F / 8;
+    const long total = N * T * f8;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const long nt = o / f8;
+        const int f0 = (int)(o - nt * f8) * 8;
+        const long n = nt / T;
+        const int t = (int)(nt - n * T);
+        const float* s = x + n * F * T + (long)f0 * T + t;
+        uint4 v;
+        v.x = pk2(s[0], s[T]); v.y = pk2(s[2L * T], s[3L * T]); v.z = pk2(s[4L * T], s[5L * T]); v.w = pk2(s[6L * T], s[7L * T]);
+        xp[o] = v;
+    }
+}
+int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_t st) {
+    REGT_CHECK_ARG(F % 8 == 0, "pack_x (bf16 rows): F = %d must be a multiple of 8", F);
+    const long total = (long)N * T * (F / 8);
+    int blocks = cdiv(total, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(pack_x_bf16_kernel, dim3(blocks), dim3(256), 0, st, x, reinterpret_cast<uint4*>(xp), (long)N, F, T);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+// n8 groups of 8 fp32 -> 8 bf16 (packed rows handed over as fp32 by a caller of regt_forward_packed)
+__global__ void cvt_rows_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long n8) {
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n8; o += (long)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * o], b = src[2 * o + 1];
+        dst[o] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+    }
+}
+int launch_cvt_rows_bf16(const float* src, void* dst, long n, hipStream_t st) {
+    REGT_CHECK_ARG(n % 8 == 0, "cvt_rows_bf16: element count must be a multiple of 8");
+    int blocks = cdiv(n / 8, 256);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+
 template <int G, int CH>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ X,
@@ -231,15 +279,198 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
     }
 }
 
+// ---- row-block variant: the CSR entries of a workgroup's rows live in LDS, the workgroup walks ALL column panels ------------
+// The panel kernels above read a row's (col, weight, weight) entries again for every panel: 6 x 13 MB at cfg-3, and those
+// streams compete with the X slice for the XCD's 4 MiB L2.  Here a workgroup owns GROUPS x rpg consecutive-ish rows of its
+// XCD's node chunk for the whole launch: it copies their entries to LDS once (one coalesced pass over the CSR: 13 MB in total)
+// and then walks panel 0, 1, ... over them.  rpg is chosen on the host so that ALL workgroups of an XCD are resident at
+// once (8 per CU): they start together and advance through the panels at about the same pace, so the live slice of X per
+// XCD is still ~one panel wide (speed only -- nothing depends on the pacing).  A lane group of PL lanes owns one row at a time;
+// it reads entries back with broadcast ds_read_b128 (no shuffles) and keeps 8 gathers in flight.  Rows of X / Y are addressed
+// through buffer descriptors: 32-bit byte offsets, the panel offset is the instruction's scalar offset.
+// BF: rows of X and of both outputs hold bf16 (16 bytes = 8 elements per lane), accumulation in fp32, one rounding at the end.
+struct SpEnt { int col; float wa, wl; int pad; };
+template <bool BF> struct SpAcc { float v[BF ? 8 : 4]; };
+template <bool BF>
+__device__ __forceinline__ void sp_fma(SpAcc<BF>& a, float w, const u32x4_t& x) {
+    if constexpr (BF) {
+        a.v[0] = fmaf(w, __uint_as_float(x.x << 16), a.v[0]); a.v[1] = fmaf(w, __uint_as_float(x.x & 0xffff0000u), a.v[1]);
+        a.v[2] = fmaf(w, __uint_as_float(x.y << 16), a.v[2]); a.v[3] = fmaf(w, __uint_as_float(x.y & 0xffff0000u), a.v[3]);
+        a.v[4] = fmaf(w, __uint_as_float(x.z << 16), a.v[4]); a.v[5] = fmaf(w, __uint_as_float(x.z & 0xffff0000u), a.v[5]);
+        a.v[6] = fmaf(w, __uint_as_float(x.w << 16), a.v[6]); a.v[7] = fmaf(w, __uint_as_float(x.w & 0xffff0000u), a.v[7]);
+    } else {
+        a.v[0] = fmaf(w, __uint_as_float(x.x), a.v[0]); a.v[1] = fmaf(w, __uint_as_float(x.y), a.v[1]);
+        a.v[2] = fmaf(w, __uint_as_float(x.z), a.v[2]); a.v[3] = fmaf(w, __uint_as_float(x.w), a.v[3]);
+    }
+}
+template <bool BF>
+__device__ __forceinline__ u32x4_t sp_pack(const SpAcc<BF>& a) {
+    if constexpr (BF) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        u32x4_t r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2_t p = {a.v[2 * i], a.v[2 * i + 1]};
+            r[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2_t));
+        }
+        return r;
+    } else {
+        return u32x4_t{__float_as_uint(a.v[0]), __float_as_uint(a.v[1]), __float_as_uint(a.v[2]), __float_as_uint(a.v[3])};
+    }
+}
+// LDS entries per workgroup (16 B each, behind the 260-int row pointer slice): what 8 (fp32 rows, 64 VGPRs) or 5 (bf16 rows, 84 VGPRs)
+// resident workgroups per CU leave each of them
+static int rows_cap(bool bf) { return (163840 / (bf ? 5 : 8) - 260 * 4 - 64) / 16; }
+
+template <int PL, bool DUAL, bool BF>
+__global__ __launch_bounds__(256, BF ? 5 : 8) void spmm_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                        const float* __restrict__ val_a, const float* __restrict__ val_l,
+                                                        const void* __restrict__ X, void* __restrict__ YA, void* __restrict__ YL,
+                                                        int nnodes, unsigned x_bytes, unsigned y_bytes, int rowbytes, int npanels, int rpg, int cap) {
+    constexpr int GROUPS = 256 / PL;
+    extern __shared__ __attribute__((aligned(16))) int sp_lds[];
+    int* rp = sp_lds;
+    SpEnt* ents = reinterpret_cast<SpEnt*>(sp_lds + 260);
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int q = nnodes / 8, r8 = nnodes % 8;
+    const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int csz = q + (xcd < r8 ? 1 : 0);
+    const int rows_wg = GROUPS * rpg;
+    const int rb = li * rows_wg;                       // first row of the workgroup inside the chunk
+    if (rb >= csz) return;
+    const int nrows = csz - rb < rows_wg ? csz - rb : rows_wg;
+    const int row0 = c0 + rb;
+    const int tid = threadIdx.x, g = tid / PL, gl = tid % PL;
+    const int first = rowptr[row0], last = rowptr[row0 + nrows];
+    const int ntile = last - first;
+    const bool in_lds = ntile <= cap;          // (workgroup-uniform) else: entries are read from global memory again per panel
+    if (tid <= nrows) rp[tid] = rowptr[row0 + tid] - first;
+    if (in_lds) {
+        for (int i = tid; i < ntile; i += 256) {
+            SpEnt e;
+            e.col = col[first + i]; e.wa = val_a[first + i]; e.wl = DUAL ? val_l[first + i] : 0.f; e.pad = 0;
+            ents[i] = e;
+        }
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(X), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sa = __builtin_amdgcn_make_buffer_rsrc(YA, 0, y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sl = __builtin_amdgcn_make_buffer_rsrc(DUAL ? YL : YA, 0, y_bytes, 0x00020000);
+    for (int p = 0; p < npanels; ++p) {
+        const int soff = p * PL * 16;
+        for (int k = 0; k < rpg; ++k) {
+            const int rl = g + GROUPS * k;
+            if (rl >= nrows) break;                     // whole lane group leaves together
+            const int beg = rp[rl], end = rp[rl + 1];
+            SpAcc<BF> aa, al;
+#pragma unroll
+            for (int i = 0; i < (BF ? 8 : 4); ++i) { aa.v[i] = 0.f; al.v[i] = 0.f; }
+            for (int e = beg; e < end; e += 8) {
+                u32x4_t x[8];
+                float wa[8], wl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = e + j < end;
+                    SpEnt en{0, 0.f, 0.f, 0};
+                    if (ok) {
+                        if (in_lds) en = ents[e + j];
+                        else { en.col = col[first + e + j]; en.wa = val_a[first + e + j]; en.wl = DUAL ? val_l[first + e + j] : 0.f; }
+                    }
+                    wa[j] = en.wa; wl[j] = en.wl;
+                    x[j] = ok ? __builtin_amdgcn_raw_buffer_load_b128(sx, (unsigned)en.col * (unsigned)rowbytes + gl * 16, soff, 0) : u32x4_t{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sp_fma<BF>(aa, wa[j], x[j]);
+                    if (DUAL) sp_fma<BF>(al, wl[j], x[j]);
+                }
+            }
+            // streaming stores: the outputs must not evict the XCD's slice of X from its L2 (aux bit 1 = nt)
+            const unsigned yo = (unsigned)(row0 + rl) * (unsigned)rowbytes + gl * 16 + soff;
+            __builtin_amdgcn_raw_buffer_store_b128(sp_pack<BF>(aa), sa, yo, 0, 2);
+            if (DUAL) __builtin_amdgcn_raw_buffer_store_b128(sp_pack<BF>(al), sl, yo, 0, 2);
+        }
+    }
+}
+
+// host side of the row-block kernel: eligibility and the rows-per-group choice
+static int rows_rpg(int nnodes, int PL, bool bf) {
+    const int chunk = cdiv(nnodes, 8), groups = 256 / PL;
+    int rpg = cdiv(chunk, groups * (bf ? 150 : 240));     // all workgroups of an XCD resident at once: 32 CUs x 8 (5) workgroups, some slack
+    if (rpg < 1) rpg = 1;
+    return rpg;
+}
+template <bool DUAL, bool BF>
+static int launch_spmm_rows(const int* rowptr, const int* col, const float* val_a, const float* val_l, const void* X, void* YA, void* YL,
+                            int nnodes, long x_rows, int rowbytes, int PL, hipStream_t st) {
+    const int npanels = rowbytes / (PL * 16);
+    const int rpg = rows_rpg(nnodes, PL, BF);
+    const int cap = rows_cap(BF);
+    const int nrb = cdiv(cdiv(nnodes, 8), (256 / PL) * rpg);
+    const long grid = 8L * nrb;
+    const unsigned xb = (unsigned)(x_rows * rowbytes), yb = (unsigned)((long)nnodes * rowbytes);
+    const int lds = cap * 16 + 260 * 4;
+    if (PL == 16)
+        hipLaunchKernelGGL((spmm_rows_kernel<16, DUAL, BF>), dim3((unsigned)grid), dim3(256), lds, st, rowptr, col, val_a, val_l, X, YA, YL,
+                           nnodes, xb, yb, rowbytes, npanels, rpg, cap);
+    else
+        hipLaunchKernelGGL((spmm_rows_kernel<8, DUAL, BF>), dim3((unsigned)grid), dim3(256), lds, st, rowptr, col, val_a, val_l, X, YA, YL,
+                           nnodes, xb, yb, rowbytes, npanels, rpg, cap);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+// REGT_SPMM_ROWS: 1 = row-block kernel where eligible (default), 0 = panel kernels only (A/B timing)
+static int g_rows_opt = -1;
+static bool rows_wanted() {
+    if (g_rows_opt < 0) { const char* e = getenv("REGT_SPMM_ROWS"); g_rows_opt = e ? atoi(e) : 1; }
+    return g_rows_opt != 0;
+}
+int spmm_rows_option(int value) {       // regt_set_option("spmm_rows", v): returns the previous setting
+    const int prev = rows_wanted() ? 1 : 0;
+    g_rows_opt = value ? 1 : 0;
+    return prev;
+}
+// eligible: rows are whole panels, every byte offset fits 32 bits, at most 256 rows per workgroup
+static bool rows_ok(int nnodes, long x_rows, long rowbytes, int PL) {
+    return rows_wanted() && rowbytes % (PL * 16) == 0 && x_rows * rowbytes < (1L << 32) - 4096 && (long)nnodes * rowbytes < (1L << 32) - 4096 &&
+           (256 / PL) * rows_rpg(nnodes, PL, false) <= 256;      // the row pointer slice in LDS holds 256 rows
+}
+
+int launch_spmm_dual_bf16(const int* rowptr, const int* col, const float* val_a, const float* val_l, const void* X, void* YA, void* YL,
+                          int nnodes, int x_rows, int W, hipStream_t st) {
+    REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 64 == 0, "spmm_dual (bf16 rows): width %d must be a multiple of 64 elements", W);
+    const long rowbytes = 2L * W;
+    static int pl_env = -1;
+    if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
+    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && rowbytes % 256 == 0;
+    const int PL = wide ? 16 : 8;
+    REGT_CHECK_ARG(x_rows * rowbytes < (1L << 32) - 4096 && (256 / PL) * rows_rpg(nnodes, PL, true) <= 256, "spmm_dual (bf16 rows): problem too large for 32-bit row offsets");
+    return launch_spmm_rows<true, true>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, (int)rowbytes, PL, st);
+}
+
 int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
                      float* YL, int nnodes, int W, hipStream_t st) {
+    return launch_spmm_dual_x(rowptr, col, val_a, val_l, X, YA, YL, nnodes, nnodes, W, st);
+}
+
+int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
+                       float* YL, int nnodes, int x_rows, int W, hipStream_t st) {
     REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 32 == 0, "spmm_dual: width %d must be a multiple of 32 floats", W);
     const int W4 = W / 4;
+    {
+        static int pl_env0 = -1;
+        if (pl_env0 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env0 = e ? atoi(e) : 0; }
+        const bool wide0 = (pl_env0 ? pl_env0 == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;
+        const int PL0 = wide0 ? 16 : 8;
+        if (rows_ok(nnodes, x_rows, 4L * W, PL0))
+            return launch_spmm_rows<true, false>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, 4 * W, PL0, st);
+    }
     static int pl_env = -1;
     if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
     // two cache lines per neighbour (halves the CSR re-reads) while the XCD's slice of X (chunk x 256 B) stays
     // around the 4 MiB L2: measured 182 vs 197 us at cfg-3 (3.2 MB slice)
-    const bool wide = pl_env ? pl_env == 16 : (W4 % 16 == 0 && (long)cdiv(nnodes, 8) * 256 <= (7L << 19));
+    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
     const int PL = wide ? 16 : 8;
     const int npanels = W4 / PL;
     const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
@@ -286,10 +517,17 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
     // Panel variant when the X matrix cannot live in the XCDs' L2s anyway and rows are whole cache lines.
     if (W4 % 8 == 0 && (long)nrows_x * W * 4 > (24L << 20) && nrows / nstack >= 4096) {
         const int nnodes = nrows / nstack;
+        if (nstack == 1) {      // one operator: the row-block kernel (CSR entries in LDS, the workgroup walks all panels)
+            static int pl_env1 = -1;
+            if (pl_env1 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env1 = e ? atoi(e) : 0; }
+            const bool wide1 = (pl_env1 ? pl_env1 == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;
+            if (rows_ok(nnodes, nrows_x, 4L * W, wide1 ? 16 : 8))
+                return launch_spmm_rows<false, false>(rowptr, col, val, nullptr, X, Y, nullptr, nnodes, nrows_x, 4 * W, wide1 ? 16 : 8, st);
+        }
         // 256-byte panels (half the passes over the CSR) while an XCD's slice of X (chunk x 256 B) stays around its 4 MiB L2
         static int pl_env = -1;
         if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-        const bool wide = pl_env ? pl_env == 16 : (W4 % 16 == 0 && (long)cdiv(nnodes, 8) * 256 <= (7L << 19));
+        const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
         const int PL = wide ? 16 : 8;
         const int npanels = W4 / PL;
         const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);

@@ -134,14 +134,18 @@ class HaloPipeline:
         pipe.release(slot)                  # the slot may be overwritten once this point is reached
     """
 
-    def __init__(self, shard: "Shard", periods: int, features: int, device, group=None):
+    def __init__(self, shard: "Shard", periods: int, features: int, device, group=None, dtype=torch.float32):
+        """``dtype`` torch.bfloat16: pack and exchange the rows as bf16 (REGT_GEMM_MODE=bf16 -- x only ever feeds bf16 matrix-core
+        operands there): half the bytes on the xGMI links, and ``forward_packed`` takes the buffer without a conversion."""
         from . import ops
-        self._pack = ops.pack_x_into
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("HaloPipeline: dtype must be float32 or bfloat16")
+        self._pack = ops.pack_x_into if dtype == torch.float32 else ops.pack_x_bf16_into
         self.shard, self.group = shard, group
         self.T, self.F = periods, features
         self.stream = torch.cuda.Stream(device)
         rows = shard.topo.x_rows
-        self.buf = [torch.empty(rows, periods, features, dtype=torch.float32, device=device) for _ in range(2)]
+        self.buf = [torch.empty(rows, periods, features, dtype=dtype, device=device) for _ in range(2)]
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.free = [torch.cuda.Event() for _ in range(2)]
         for e in self.free:

@@ -122,8 +122,9 @@ class RegTGCNFunction(torch.autograd.Function):
         lib = _lib.load()
         if not x.is_cuda:
             raise _lib.RegtError("RegT-GCN forward needs CUDA/HIP tensors: there is no CPU path in this package")
-        if x.dtype != torch.float32 or x.dim() != 3:
-            raise ValueError(f"x must be float32 (N,F,T), got {x.dtype} {tuple(x.shape)}")
+        xbf = packed and x.dtype == torch.bfloat16        # region shard that packs and exchanges its rows as bf16 (REGT_GEMM_MODE=bf16)
+        if (x.dtype != torch.float32 and not xbf) or x.dim() != 3:
+            raise ValueError(f"x must be float32 (N,F,T) (or packed bfloat16 (x_rows,T,F)), got {x.dtype} {tuple(x.shape)}")
         names = param_names(regional)
         if len(params) != len(names):
             raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
@@ -136,6 +137,8 @@ class RegTGCNFunction(torch.autograd.Function):
         # gradient columns (ds^T x_pad = 0) are sliced off in the backward.
         f_real = x.shape[2] if packed else x.shape[1]
         f_pad = (-f_real) % 4
+        if f_pad and xbf:
+            raise ValueError("bf16 packed input needs a feature width that is a multiple of 4")
         if f_pad:
             x = torch.nn.functional.pad(x, (0, f_pad) if packed else (0, 0, 0, f_pad)).contiguous()
             params = tuple(torch.nn.functional.pad(p_, (0, f_pad)).contiguous() if n_ in F_WIDE_PARAMS else p_
@@ -152,7 +155,7 @@ class RegTGCNFunction(torch.autograd.Function):
                 raise ValueError(f"x has {N} nodes but the prepared graph has {graph.num_nodes}")
         # shape validation, the dims / parameter-pointer structs and the workspace size only depend on (shapes, parameter
         # addresses): remembered per graph, so a steady-state step skips ~60 us of Python (TPIMS-scale steps are host-bound)
-        plan_key = (N, T, F, x_rows, regional, float(slope), tuple(p_.data_ptr() for p_ in params))
+        plan_key = (N, T, F, x_rows, regional, float(slope), tuple((p_.data_ptr(), tuple(p_.shape)) for p_ in params))
         plans = graph.__dict__.setdefault("_plan_cache", {})
         plan = plans.get(plan_key)
         if plan is None:
@@ -184,7 +187,10 @@ class RegTGCNFunction(torch.autograd.Function):
         ws = handle.ws
         pred = torch.empty(N, O, dtype=torch.float32, device=x.device)
         hidden = torch.empty(N, Cdim, dtype=torch.float32, device=x.device)
-        if packed:
+        if xbf:
+            _lib.check(lib.regt_forward_packed_bf16(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), x_rows, _lib.ptr(pred),
+                                                    _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward_packed_bf16")
+        elif packed:
             _lib.check(lib.regt_forward_packed(C.byref(dims), C.byref(gs), C.byref(ps), _lib.ptr(x), x_rows, _lib.ptr(pred),
                                                _lib.ptr(hidden), _lib.ptr(ws), wsb, _stream()), "regt_forward_packed")
         else:

@@ -39,6 +39,31 @@ def pack_x_into(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def pack_x_bf16_into(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """(N,F,T) fp32 -> rows [0, N) of the bf16 tensor ``out`` (>= N rows of (T,F)), rounded to nearest even (REGT_GEMM_MODE=bf16:
+    the packed rows a region shard exchanges and hands to ``forward_packed``); F % 8 == 0."""
+    x = _f32c(x, "x")
+    n, f, t = x.shape
+    if (out.dtype != torch.bfloat16 or not out.is_contiguous() or out.device != x.device or out.dim() != 3
+            or out.shape[0] < n or tuple(out.shape[1:]) != (t, f)):
+        raise ValueError(f"pack_x_bf16_into: out must be a contiguous bf16 (>= {n}, {t}, {f}) tensor on {x.device}")
+    _lib.check(_lib.load().regt_pack_x_bf16(_lib.ptr(x), _lib.ptr(out), n, f, t, _stream()), "regt_pack_x_bf16")
+    return out
+
+
+def spmm_dual_bf16(rowptr, col, val_a, val_l, x: torch.Tensor):
+    """(A x, L x) as bf16 rows from bf16 rows ``x`` (x_rows >= N, W): fp32 accumulation, one rounding per element; W % 64 == 0."""
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 2:
+        raise _lib.RegtError("x must be a 2-D bfloat16 CUDA tensor (no CPU path)")
+    x = x.contiguous()
+    n = rowptr.numel() - 1
+    ya = torch.empty(n, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    yl = torch.empty_like(ya)
+    _lib.check(_lib.load().regt_spmm_dual_bf16(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(val_a), _lib.ptr(val_l), _lib.ptr(x),
+                                               _lib.ptr(ya), _lib.ptr(yl), n, x.shape[0], x.shape[1], _stream()), "regt_spmm_dual_bf16")
+    return ya, yl
+
+
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torch.Tensor, out: Optional[torch.Tensor] = None):
     """Y[r,:] = sum_e val[e] * X[col[e],:] for r in range(len(rowptr)-1)."""
     x = _f32c(x, "x")

@@ -53,20 +53,24 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None, store=None):
+def forward_fused(p, x, a_hat, l_list, regional=True, rnd=None, store=None, round_x=False):
     """x (N,F,T).  Returns (pred, hidden) through the composed-weight formulation using autograd.
 
     ``rnd``: optional rounding applied to both operands of every activation x weight contraction that the HIP path
     runs on the matrix cores (``bf16_round`` emulates REGT_GEMM_MODE=bf16; accumulation, SpMM, compositions, gate
     math and the skinny last head layer stay fp32, as in the kernels).  ``store``: rounding applied to the M x C
     activations the pipeline keeps in HBM between kernels (h, Z; ``bf16_round`` when that mode stores them as bf16):
-    whatever reads them later -- the GRU blend here -- sees the stored value."""
+    whatever reads them later -- the GRU blend here -- sees the stored value.  ``round_x``: the snapshot itself is rounded
+    before it is aggregated (bf16 rows of x / A_hat x / L~ x, the cfg-5 layout of SURVEY 8(d): where the fused forward kernel
+    applies the packing kernel rounds x once and the aggregation reads and writes bf16 rows)."""
     q = (lambda v: v) if rnd is None else rnd
     st = (lambda v: v) if store is None else store
     n, f, t = x.shape
     R = len(l_list)
     w = compose(p, R, regional)
     xp = x.permute(0, 2, 1)                              # (N,T,F) packed rows
+    if round_x:
+        xp = q(xp)
     ax = torch.einsum("ij,jtf->itf", a_hat, xp)
     pre = q(xp) @ q(w["A0"]).t() + w["b"]
     for r in range(R):

@@ -1,0 +1,137 @@
+"""bf16 rows of x / A_hat x / L~ x and the fused forward kernel of the bf16 arithmetic (REGT_GEMM_MODE=bf16, csrc/fused.hip).
+
+The fused kernel replaces three launches (regional embedding, gates, candidate: RegionalTemporalGCN.py:136-148,
+models/utils.py:168-188) and is built to reproduce their arithmetic exactly: same bf16 MFMA operands, same k order, same fp32
+gate math, same rounding points, same per-node summation order.  So the checks here are BIT-FOR-BIT: with a snapshot that is
+bf16-representable (the three-launch path then rounds x, A_hat x and L~ x at LDS staging to the very values the bf16-row path
+stores), forward outputs and every gradient of the two paths must be identical.  The oracle-level tolerance of the mode
+itself is tests/test_gpu_bf16.py's business."""
+import numpy as np
+import pytest
+import torch
+
+from fused_math import bf16_round
+from oracle import model as M
+from test_gpu_model import _synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16_mode():
+    import regtgcn_amd as R
+    lib = R.load_library()
+    prev = lib.regt_set_gemm_mode(2)
+    yield R
+    lib.regt_set_gemm_mode(prev)
+    lib.regt_set_option(b"xbf", 1)
+    lib.regt_set_option(b"spmm_rows", 1)
+
+
+def test_pack_x_bf16_rounds_to_nearest_even_and_leaves_halo_rows_alone():
+    import regtgcn_amd as R
+    x = torch.rand(777, 64, 12, device="cuda") * 3 - 1
+    out = torch.full((777 + 9, 12, 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    R.ops.pack_x_bf16_into(x, out)
+    assert torch.equal(out[:777], x.permute(0, 2, 1).contiguous().to(torch.bfloat16))
+    assert bool((out[777:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,e,regions,w,extra", [(5000, 40000, 4, 768, 0), (20000, 150000, 8, 384, 333), (300, 2000, 2, 64, 5),
+                                                  (9, 30, 2, 128, 0)])
+def test_bf16_row_aggregation_is_the_rounded_fp32_aggregation(n, e, regions, w, extra):
+    """regt_spmm_dual_bf16 on bf16 rows == regt_spmm_dual on the same values as fp32, rounded once: same CSR order, fp32 sums."""
+    import regtgcn_amd as R
+    ei, ri, rw, _ = _synthetic(n, e, regions, 4, 1, seed=n)
+    g = R.prepare_graph(ei.cuda(), None, [i.cuda() for i in ri], [a.cuda() for a in rw], n)
+    x = torch.randn(n + extra, w, device="cuda").to(torch.bfloat16)
+    ya, yl = R.ops.spmm_dual_bf16(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
+    if w % 32 == 0:
+        fa, fl = R.ops.spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x[:n].float().contiguous())
+    # reference sums in float64 from the CSR itself (also covers halo columns: none here, but x has extra rows)
+    rp, col = g.m_rowptr.cpu().long(), g.m_col.cpu().long()
+    rows = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    xd = x.float().cpu().double()
+    for got, val in ((ya, g.m_val_a), (yl, g.m_val_l)):
+        want = torch.zeros(n, w, dtype=torch.float64).index_add_(0, rows, val.cpu().double()[:, None] * xd[col])
+        err = (got.float().cpu().double() - want).abs()
+        assert bool((err <= 2.0 ** -8 * want.abs() + 1e-6).all())           # one bf16 rounding of an fp32 sum
+    if w % 32 == 0:
+        assert torch.equal(ya, fa.to(torch.bfloat16)) and torch.equal(yl, fl.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("n,e,regions,w", [(20000, 200000, 8, 384), (4096, 30000, 3, 96 * 4)])
+def test_row_block_kernel_equals_panel_kernel_bit_for_bit(n, e, regions, w):
+    import regtgcn_amd as R
+    lib = R.load_library()
+    ei, ri, rw, _ = _synthetic(n, e, regions, 4, 1, seed=n + 1)
+    g = R.prepare_graph(ei.cuda(), None, [i.cuda() for i in ri], [a.cuda() for a in rw], n)
+    x = torch.randn(n, w, device="cuda")
+    try:
+        lib.regt_set_option(b"spmm_rows", 1)
+        a1, l1 = R.ops.spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
+        lib.regt_set_option(b"spmm_rows", 0)
+        a0, l0 = R.ops.spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
+    finally:
+        lib.regt_set_option(b"spmm_rows", 1)
+    assert torch.equal(a1, a0) and torch.equal(l1, l0)
+
+
+def _run(R, n, e, regions, f, t, o, xbf, seed=0):
+    lib = R.load_library()
+    lib.regt_set_option(b"xbf", xbf)
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n + seed)
+    x = bf16_round(x)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
+    mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+    mod.load_state_dict(p, strict=True)
+    mod = mod.cuda()
+    pred, hidden = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    (torch.mean((pred - y.cuda()) ** 2) + 1e-3 * hidden.sum()).backward()
+    grads = {k: q.grad.detach().clone() for k, q in mod.named_parameters() if q.grad is not None}
+    return pred.detach(), hidden.detach(), grads
+
+
+# (nodes, edges, regions, F, T, O): 64 regions = configs[4]; O = 3; T = 5 and a row count that is no multiple of 64 (tail tile,
+# tiles that start inside a node); T = 48 (a node spans two 64-row tiles); one region per ~100 nodes (tiles with two regions)
+FUSED_SHAPES = [(2048, 20000, 64, 64, 12, 1), (1200, 9000, 4, 64, 12, 3), (701, 5000, 3, 64, 5, 1), (400, 3000, 2, 64, 48, 1),
+                (600, 4000, 6, 64, 1, 1)]
+
+
+@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES)
+def test_fused_forward_equals_three_launch_path_bit_for_bit(bf16_mode, n, e, regions, f, t, o):
+    R = bf16_mode
+    p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1)
+    p0, h0, g0 = _run(R, n, e, regions, f, t, o, 0)
+    worst = {"pred": float((p1 - p0).abs().max()), "hidden": float((h1 - h0).abs().max())}
+    worst.update({k: float((g1[k] - g0[k]).abs().max()) for k in g0})
+    bad = {k: v for k, v in worst.items() if v != 0.0}
+    assert not bad, bad
+    assert float(h1.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+def test_packed_bf16_rows_equal_packed_fp32_rows(bf16_mode):
+    """Region-shard entry: bf16 rows packed by the caller (regt_pack_x_bf16 -> regt_forward_packed_bf16) give the results of the
+    fp32 packed rows (converted inside regt_forward_packed) bit for bit; halo rows are present but unread here."""
+    R = bf16_mode
+    lib = R.load_library()
+    lib.regt_set_option(b"xbf", 1)
+    n, e, regions, f, t, o = 1500, 12000, 5, 64, 12, 1
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=5)
+    y = torch.rand(n, o).cuda()
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
+    outs = []
+    for dt in (torch.float32, torch.bfloat16):
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        ext = torch.zeros(n + 40, t, f, dtype=dt, device="cuda")
+        (R.ops.pack_x_into if dt == torch.float32 else R.ops.pack_x_bf16_into)(x.cuda(), ext)
+        pred, hidden = mod.forward_packed(ext, graph)
+        torch.mean((pred - y) ** 2).backward()
+        outs.append((pred.detach(), hidden.detach(), {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k

@@ -30,11 +30,21 @@ ya = torch.empty(nodes, W, device=dev); yl = torch.empty_like(ya)
 from regtgcn_amd import _lib
 lib = _lib.load(); st = torch.cuda.current_stream().cuda_stream
 dual = lambda: _lib.check(lib.regt_spmm_dual(_lib.ptr(pg.m_rowptr), _lib.ptr(pg.m_col), _lib.ptr(pg.m_val_a), _lib.ptr(pg.m_val_l), _lib.ptr(x), _lib.ptr(ya), _lib.ptr(yl), nodes, W, st), "dual")
-ms = t(dual)
-ms_cold = t_cold(dual)
 nnz = pg.m_col.numel()
 algo = nodes*W*4 + nnz*12 + (nodes+1)*4 + 2*nodes*W*4
-print(f"dual  PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}   cold: {ms_cold*1e3:7.1f} us")
+for rows in (1, 0):          # row-block kernel (CSR entries in LDS) vs column-panel kernel
+    lib.regt_set_option(b"spmm_rows", rows)
+    ms = t(dual)
+    ms_cold = t_cold(dual)
+    print(f"dual  rows={rows} PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}   "
+          f"cold: {ms_cold*1e3:7.1f} us = {algo/ms_cold/1e6/8000:.3f} of 8 TB/s")
+lib.regt_set_option(b"spmm_rows", 1)
+# bf16 rows (REGT_GEMM_MODE=bf16, cfg-5 layout): same row bytes at twice the feature count
+xb = torch.rand(nodes, 2 * W, device=dev).to(torch.bfloat16)
+yab = torch.empty_like(xb); ylb = torch.empty_like(xb)
+dualb = lambda: _lib.check(lib.regt_spmm_dual_bf16(_lib.ptr(pg.m_rowptr), _lib.ptr(pg.m_col), _lib.ptr(pg.m_val_a), _lib.ptr(pg.m_val_l), _lib.ptr(xb), _lib.ptr(yab), _lib.ptr(ylb), nodes, nodes, 2 * W, st), "dual bf16")
+ms = t(dualb); ms_cold = t_cold(dualb)
+print(f"dual  bf16 rows W={2*W}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic   cold: {ms_cold*1e3:7.1f} us = {algo/ms_cold/1e6/8000:.3f} of 8 TB/s")
 
 
 # ---- reference-faithful WIDE aggregation: a learned hidden state of width T*512 (ConvStackedTemporalGCN layers 2-5, models/
@@ -44,7 +54,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "wide":
     op = R.graph.prepare_gcn_operator(g.edge_index.to(dev), g.edge_attr.to(dev), nodes)
     h = torch.rand(nodes, Wd, device=dev)
     out = torch.empty_like(h)
-    for name, (rp, cl, vl) in (("A_hat  ", (op.rowptr, op.col, op.val)), ("A_hat^T", (op.t_rowptr, op.t_col, op.t_val))):
+    for rows, name, (rp, cl, vl) in ((1, "A_hat  ", (op.rowptr, op.col, op.val)), (1, "A_hat^T", (op.t_rowptr, op.t_col, op.t_val)),
+                                     (0, "A_hat  ", (op.rowptr, op.col, op.val))):
+        lib.regt_set_option(b"spmm_rows", rows)
+        name = f"{name} rows={rows}"
         fn = lambda: _lib.check(lib.regt_spmm_csr(_lib.ptr(rp), _lib.ptr(cl), _lib.ptr(vl), _lib.ptr(h), _lib.ptr(out), nodes, nodes, Wd, st), "spmm")
         ms = t(fn, 10)
         nz = cl.numel()
