@@ -290,6 +290,11 @@ int32_t regt_set_gemm_mode(int32_t mode);
  * kernel (CSR entries of a workgroup's rows held in LDS); 0 = the column-panel kernels. */
 int32_t regt_set_option(const char* name, int32_t value);
 
+/* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row
+ * tile (start, tables, h, R / q, Z_0, candidate_0, Z_1, candidate_1), copied to out_host; synchronises the device.  Returns
+ * the number of values written, 0 when tracing is off. */
+int64_t regt_debug_trace(int64_t* out_host, int64_t capacity);
+
 /* Per-stage timing with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures).  collect() waits for the recorded events and writes "name count total_ms"
  * lines into buf. */

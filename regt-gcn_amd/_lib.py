@@ -96,6 +96,7 @@ SIGNATURES = {
     "regt_gat_forward": (C.c_int32, [vp, vp, vp, vp, vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]),
     "regt_gat_backward": (C.c_int32, [vp, vp, vp, vp, vp, vp, C.c_float, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp]),
     "regt_graph_stats": (C.c_int32, [C.POINTER(C.c_int64)]),
+    "regt_debug_trace": (C.c_int64, [C.POINTER(C.c_int64), C.c_int64]),
     "regt_profile_enable": (C.c_int32, [C.c_int32]),
     "regt_profile_collect": (C.c_int32, [C.c_char_p, C.c_size_t]),
     "regt_mse_loss_grad": (C.c_int32, [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]),

@@ -1249,6 +1249,8 @@ int32_t regt_mean_csr(const int64_t* ei, int64_t E, int32_t N, int32_t* rowptr, 
     return graph_mean_csr(ei, (long)E, N, rowptr, col, val, flags_dev, ws, ws_bytes, (hipStream_t)st);
 }
 
+int64_t regt_debug_trace(int64_t* out_host, int64_t capacity) { return fused_trace_fetch(reinterpret_cast<long*>(out_host), (long)capacity); }
+
 int32_t regt_profile_enable(int32_t on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;

@@ -24,6 +24,8 @@
 // Arithmetic, rounding points and summation orders are exactly those of the three-launch path (bf16 MFMA operands, fp32
 // accumulate over k in ascending 16-k blocks, fp32 gate math, one rounding per stored element, per-node partial sums over a
 // 64-row block in row order): with the same bf16 inputs both paths give bit-identical results (tests/test_gpu_fused.py).
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "gemm_split.h"
 
@@ -66,7 +68,7 @@ __device__ __forceinline__ bf16x8 f_ldfrag(__amdgpu_buffer_rsrc_t r, int voff, i
 }
 
 constexpr int FT_ROWS = 64;              // rows of a tile
-constexpr int FT_IMG_LD = 132;           // floats per image row (128 columns + 4: conflict-free 16-byte reads)
+constexpr int FT_IMG_LD = 36;            // floats per row of a wave's image (its 32 columns + 4)
 constexpr int FT_IMG_ROWS = 16;
 
 }  // namespace
@@ -75,8 +77,8 @@ template <int C, int F>
 struct FusedFwdLds {
     static constexpr int PLANE_B = FT_ROWS * 32;                 // one 16-k block of 64 rows
     static constexpr int OPER_B = (C / 16) * PLANE_B;            // h (or q) of the tile as an A operand
-    static constexpr int IMG_OFF = 2 * OPER_B;
-    static constexpr int TAB_OFF = IMG_OFF + FT_IMG_ROWS * FT_IMG_LD * 4;
+    static constexpr int IMG_OFF = 2 * OPER_B;                   // four wave-private 16-row fp32 images
+    static constexpr int TAB_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
     static constexpr int BYTES = TAB_OFF + FT_ROWS * (int)sizeof(FRow) + FT_ROWS * 4 + (FT_ROWS + 4) * 4;
 };
 
@@ -88,7 +90,6 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char flds[];
     char* Hp = flds;
     char* Qp = flds + L::OPER_B;
-    float* img = reinterpret_cast<float*>(flds + L::IMG_OFF);
     FRow* rowtab = reinterpret_cast<FRow*>(flds + L::TAB_OFF);
     int* rreg = reinterpret_cast<int*>(rowtab + FT_ROWS);
     int* ulist = rreg + FT_ROWS;                                 // [0] = number of distinct regions, then the regions
@@ -97,6 +98,38 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     const long m0 = (long)blockIdx.x * FT_ROWS;
     const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
     const long node0 = m0 / a.T;
+    // developer trace (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of thread 0 at the phase boundaries
+#define FT_MARK(i) do { if (a.trace && tid == 0) a.trace[8L * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+    FT_MARK(0);
+
+    // ---- descriptors: the tile's rows of every activation array (rows past the end are out of range: loads return 0, stores are dropped)
+    const __amdgpu_buffer_rsrc_t sX = f_rsrc(reinterpret_cast<const char*>(a.X) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
+    // (timing-only switches, REGT_FUSED_DBG: bit 0 = zero-record store descriptors: every activation store is dropped by the range
+    // check; bit 1 = zero-record weight descriptors: fragment loads return 0 without traffic -- cdna_hip_programming.md section 7)
+    const int st_on = (a.dbg & 1) ? 0 : 1, w_on = (a.dbg & 2) ? 0 : 1;
+    const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4 * st_on);
+    // A-fragment offsets of the K = F operands: lane (lr, lh) holds k = 8 lh .. 8 lh + 7 of row 32 mi + lr of a 16-k block
+    const int afo = lr * F * 2 + lh * 16;
+    // Everything phase 0 needs that does not depend on the region table is requested first (x, A_hat x, the A0 fragments): the
+    // row / region tables are computed while those loads fly.  Vector-memory operations retire in issue order (stores included
+    // -- gfx9 has one counter), so a load issued BEHIND an epilogue's stores only returns once those stores are acknowledged;
+    // hence the rule of this kernel: the fragments of the NEXT K loop are requested before the current epilogue stores.
+    bf16x8 axf[2][KBF], xf[2][KBF], lf[2][KBF], b0[2][KBF], b1[2][KBF];    // b0 / b1: fragments of A0 ([0]) and A_region ([1]) of column tile 0 / 1
+    {
+        const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) {
+            xf[0][kb] = f_ldfrag(sX, afo, kb * 32);
+            xf[1][kb] = f_ldfrag(sX, afo + 32 * F * 2, kb * 32);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) b0[0][kb] = f_ldfrag(sA0, lane * 16, (w * KBF + kb) * 1024);
+    }
     if (tid < FT_ROWS) {
         const long m = m0 + tid;
         const long node = m / a.T;
@@ -106,7 +139,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         rreg[tid] = ok ? (a.node_region ? a.node_region[node] : 0) : -1;
     }
     __syncthreads();
-    if (tid == 0) {        // distinct regions of the tile's rows, in order of first appearance (usually one)
+    // distinct regions of the tile's rows, in order of first appearance.  Usually one: wave 0 (one lane per row) votes on
+    // "differs from row 0"; only a tile that really holds several regions pays for the serial scan.
+    const bool multi = tid < FT_ROWS ? __ballot(tid < nvalid && rreg[tid] != rreg[0]) != 0 : false;
+    if (tid == 0 && !multi) { ulist[0] = 1; ulist[1] = rreg[0]; }
+    if (tid == 0 && multi) {
         int n = 0;
         for (int r = 0; r < nvalid; ++r) {
             const int g = rreg[r];
@@ -118,37 +155,37 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     }
     __syncthreads();
     const int nuniq = __builtin_amdgcn_readfirstlane(ulist[0]);
-
-    // ---- descriptors: the tile's rows of every activation array (rows past the end are out of range: loads return 0, stores are dropped)
-    const __amdgpu_buffer_rsrc_t sX = f_rsrc(reinterpret_cast<const char*>(a.X) + m0 * F * 2, (long)nvalid * F * 2);
-    const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
-    const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
-    const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2);
-    const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2);
-    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2);
-    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
-    // A-fragment offsets of the K = F operands: lane (lr, lh) holds k = 8 lh .. 8 lh + 7 of row 32 mi + lr of a 16-k block
-    const int afo = lr * F * 2 + lh * 16;
-    bf16x8 axf[2][KBF];
+    const int rg0 = __builtin_amdgcn_readfirstlane(ulist[1]);
+    {
+        const int o0 = rreg[lr] == rg0 ? afo : 0x7ffffff0, o1 = rreg[32 + lr] == rg0 ? afo + 32 * F * 2 : 0x7ffffff0;
+        const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+        for (int kb = 0; kb < KBF; ++kb) {
+            lf[0][kb] = f_ldfrag(sLX, o0, kb * 32);
+            lf[1][kb] = f_ldfrag(sLX, o1, kb * 32);
+        }
 #pragma unroll
-        for (int kb = 0; kb < KBF; ++kb) axf[mi][kb] = f_ldfrag(sAX, afo + mi * 32 * F * 2, kb * 32);
+        for (int kb = 0; kb < KBF; ++kb) b0[1][kb] = f_ldfrag(sAr, lane * 16, (w * KBF + kb) * 1024);
+    }
+    FT_MARK(1);
 
-    // epilogue thread geometry: round rnd = rows 16 rnd .. 16 rnd + 15 of the tile; thread = (row tid >> 4, columns 8 (tid & 15) ..+7)
-    const int er = tid >> 4, ec = 8 * (tid & 15);
-    auto stage = [&](const f32x16 (&acc)[2], int rnd) {          // accumulators of round rnd -> image (between two barriers)
+    // Epilogue geometry.  Every wave transposes its OWN 64 x 32 accumulator strip through a wave-private 16-row image, so an
+    // epilogue needs no workgroup barrier at all (LDS operations of one wave execute in order): round rnd = rows 16 rnd ..
+    // 16 rnd + 15 of the tile; lane = (row lane >> 2, columns 8 (lane & 3) .. + 7 of the wave's 32) = 16 bytes of a bf16 array.
+    // The same lane owns the same (row, columns) in the Z and in the candidate epilogue, which is what lets Z stay in registers.
+    // The only barriers left are the two hand-overs of the h and q planes between the waves.
+    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
+    const int er = lane >> 2, ec = 32 * w + 8 * (lane & 3);
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {          // accumulators of round rnd -> the wave's image
         const int mi = rnd >> 1, rd = rnd & 1;
-        __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
-            img[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + 32 * w + lr] = mi ? acc[1][reg] : acc[0][reg];
+            imgw[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + lr] = mi ? acc[1][reg] : acc[0][reg];
         }
-        __syncthreads();
     };
     auto img8 = [&]() {
-        const float4* p = reinterpret_cast<const float4*>(img + er * FT_IMG_LD + ec);
+        const float4* p = reinterpret_cast<const float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
         const float4 lo = p[0], hi = p[1];
         return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
     };
@@ -158,20 +195,45 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     };
     // the 16 bytes of (row, columns c .. c + 7) inside an operand's planes
     auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
-    // acc += P (planes, K = C) x W^T (fragments of column block nb), then the A_hat x part with G (column block nbg)
-    auto kloop = [&](f32x16 (&acc)[2], const char* P, const void* Wf, int nb, const void* Gf, int nbg) {
-        const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2), sG = f_rsrc(Gf, (long)0x7ffffff0);
-        bf16x8 bw[KBC], bg[KBF];
+    // B fragments of one K = C + F loop: W (C x C, column block nb) and G (column block nbg of a (rows x F) composed weight)
+    bf16x8 bw[KBC], bg[KBF];
+    auto issue_b = [&](const void* Wf, int nb, const void* Gf, int nbg) {
+        const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2 * w_on), sG = f_rsrc(Gf, (long)0x7ffffff0 * w_on);
 #pragma unroll
         for (int kb = 0; kb < KBC; ++kb) bw[kb] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) bg[kb] = f_ldfrag(sG, lane * 16, (nbg * KBF + kb) * 1024);
+    };
+    // acc = P (planes, K = C) x W^T + (A_hat x) x G^T with the fragments requested by the last issue_b
+    auto kloop = [&](f32x16 (&acc)[2], const char* P) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // A fragments from the planes, three 16-k blocks ahead of the MFMAs that consume them (an LDS round trip is ~2-3 MFMA
+        // pairs long and this wave has one partner on its SIMD); the scheduling barriers keep the reads where they are written
+        // (left alone, the scheduler sinks every read to its use)
+        const char* pa0 = P + sp_off(lr, lh);
+        const char* pa1 = P + sp_off(32 + lr, lh);
+        constexpr int AHEAD = 3;
+        bf16x8 fa[KBC + AHEAD][2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < AHEAD; ++kb) {
+            fa[kb][0] = *reinterpret_cast<const bf16x8*>(pa0 + kb * L::PLANE_B);
+            fa[kb][1] = *reinterpret_cast<const bf16x8*>(pa1 + kb * L::PLANE_B);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < KBC; ++kb) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(P + kb * L::PLANE_B + sp_off(lr, lh));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(P + kb * L::PLANE_B + sp_off(32 + lr, lh));
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bw[kb], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[kb], acc[1], 0, 0, 0);
+            if (kb + AHEAD < KBC) {
+                fa[kb + AHEAD][0] = *reinterpret_cast<const bf16x8*>(pa0 + (kb + AHEAD) * L::PLANE_B);
+                fa[kb + AHEAD][1] = *reinterpret_cast<const bf16x8*>(pa1 + (kb + AHEAD) * L::PLANE_B);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], bw[kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], bw[kb], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) {
@@ -179,43 +241,44 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axf[1][kb], bg[kb], acc[1], 0, 0, 0);
         }
     };
-    auto zero = [&](f32x16 (&acc)[2]) {
+
+    // ---- phase 0: regional embedding h = act(x A0^T + (L~ x) A_region^T + b') -> global + h planes --------------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    };
-
-    // ---- phase 0: regional embedding h = act(x A0^T + (L~ x) A_region^T + b') -> global + h planes --------------------------
-#pragma unroll 1
-    for (int j = 0; j < NT; ++j) {
-        const int nb = 4 * j + w;
-        f32x16 acc[2];
-        zero(acc);
-        {
+        static_assert(NT == 2, "phase 0 double-buffers the fragments of two column tiles");
+        if (j == 0) {           // the fragments of column tile 1 are requested before tile 0's epilogue stores
             const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
-            bf16x8 b[KBF], x[2][KBF];
+            const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
 #pragma unroll
             for (int kb = 0; kb < KBF; ++kb) {
-                b[kb] = f_ldfrag(sA0, lane * 16, (nb * KBF + kb) * 1024);
-                x[0][kb] = f_ldfrag(sX, afo, kb * 32);
-                x[1][kb] = f_ldfrag(sX, afo + 32 * F * 2, kb * 32);
-            }
-#pragma unroll
-            for (int kb = 0; kb < KBF; ++kb) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][kb], b[kb], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][kb], b[kb], acc[1], 0, 0, 0);
+                b1[0][kb] = f_ldfrag(sA0, lane * 16, ((4 + w) * KBF + kb) * 1024);
+                b1[1][kb] = f_ldfrag(sAr, lane * 16, ((4 + w) * KBF + kb) * 1024);
             }
         }
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[0][kb], j ? b1[0][kb] : b0[0][kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[1][kb], j ? b1[0][kb] : b0[0][kb], acc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[0][kb], j ? b1[1][kb] : b0[1][kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[1][kb], j ? b1[1][kb] : b0[1][kb], acc[1], 0, 0, 0);
+        }
 #pragma unroll 1
-        for (int u = 0; u < nuniq; ++u) {       // one pass per distinct region of the tile: rows of other regions contribute zeros
+        for (int u = 1; u < nuniq; ++u) {       // further regions of the tile (rare): rows of other regions contribute zeros
             const int rg = __builtin_amdgcn_readfirstlane(ulist[1 + u]);
             const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg * a.ar_stride, (long)C * F * 2);
             const int o0 = rreg[lr] == rg ? afo : 0x7ffffff0, o1 = rreg[32 + lr] == rg ? afo + 32 * F * 2 : 0x7ffffff0;
             bf16x8 b[KBF], x[2][KBF];
 #pragma unroll
             for (int kb = 0; kb < KBF; ++kb) {
-                b[kb] = f_ldfrag(sAr, lane * 16, (nb * KBF + kb) * 1024);
+                b[kb] = f_ldfrag(sAr, lane * 16, ((4 * j + w) * KBF + kb) * 1024);
                 x[0][kb] = f_ldfrag(sLX, o0, kb * 32);
                 x[1][kb] = f_ldfrag(sLX, o1, kb * 32);
             }
@@ -224,6 +287,13 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[0][kb], b[kb], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[1][kb], b[kb], acc[1], 0, 0, 0);
             }
+        }
+        if (j == NT - 1) {
+            issue_b(a.Urf, w, a.Gzrf, C / 32 + w);                          // reset gate, column tile 0
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)                                  // A_hat x: A fragments of all six K loops to come
+#pragma unroll
+                for (int kb = 0; kb < KBF; ++kb) axf[mi][kb] = f_ldfrag(sAX, afo + mi * 32 * F * 2, kb * 32);
         }
         const V8 b = bias8(a.bprime + 128 * j + ec);
         const float ns = a.act_lrelu ? a.slope : 1.0f;
@@ -240,14 +310,16 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             *reinterpret_cast<u32x4_t*>(Hp + plane_off(row, c)) = pk;
         }
     }
+    FT_MARK(2);
     __syncthreads();                                            // h planes complete
 
     // ---- phase 1: reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R -> global + q planes ---------------------------
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < NT; ++j) {
         f32x16 acc[2];
-        zero(acc);
-        kloop(acc, Hp, a.Urf, 4 * j + w, a.Gzrf, C / 32 + 4 * j + w);
+        kloop(acc, Hp);
+        if (j + 1 < NT) issue_b(a.Urf, 4 * (j + 1) + w, a.Gzrf, C / 32 + 4 * (j + 1) + w);
+        else issue_b(a.Uzf, w, a.Gzrf, w);                                  // update gate, column tile 0
         const V8 b = bias8(a.czr + C + 128 * j + ec);
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
@@ -264,16 +336,17 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             *reinterpret_cast<u32x4_t*>(Qp + plane_off(row, c)) = pq;
         }
     }
+    FT_MARK(3);
     __syncthreads();                                            // q planes complete
 
     // ---- phases 2 + 3 per column tile: update gate Z (kept in registers), candidate H~, blend, sum over the node's periods ---
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < NT; ++j) {
         u32x4_t zk[4];
         {
             f32x16 acc[2];
-            zero(acc);
-            kloop(acc, Hp, a.Uzf, 4 * j + w, a.Gzrf, 4 * j + w);
+            kloop(acc, Hp);
+            issue_b(a.Uhf, 4 * j + w, a.Ghf, 4 * j + w);                      // candidate, same column tile
             const V8 b = bias8(a.czr + 128 * j + ec);
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
@@ -286,13 +359,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
                 __builtin_amdgcn_raw_buffer_store_b128(zk[rnd], sZR, ((16 * rnd + er) * 2 * C + 128 * j + ec) * 2, 0, 0);
             }
         }
+        FT_MARK(4 + 2 * j);
         f32x16 acc[2];
-        zero(acc);
-        kloop(acc, Qp, a.Uhf, 4 * j + w, a.Ghf, 4 * j + w);
+        kloop(acc, Qp);
+        if (j + 1 < NT) issue_b(a.Uzf, 4 * (j + 1) + w, a.Gzrf, 4 * (j + 1) + w);
         const V8 b = bias8(a.ch + 128 * j + ec);
-        int cur = -1;                    // threads 0..127: running sum of column tid over the rows of node `cur`
+        int cur = -1;                    // lanes 0..31: running sum of column 32 w + lane over the rows of node `cur`
         float csum = 0.f;
-        float* oh = a.OH + node0 * C + 128 * j + tid;
+        float* oh = a.OH + node0 * C + 128 * j + 32 * w + lr;
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
@@ -305,32 +379,67 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 ht.v[i] = f_tanh(v.v[i] + b.v[i]);
-                bl.v[i] = pt * (Zv.v[i] * hv.v[i] + (1.0f - Zv.v[i]) * ht.v[i]);
+                bl.v[i] = __fmul_rn(pt, gru_blend(Zv.v[i], hv.v[i], ht.v[i]));
             }
             __builtin_amdgcn_raw_buffer_store_b128(f_pack8(ht), sHt, (row * C + c) * 2, 0, 0);
-            float4* p = reinterpret_cast<float4*>(img + er * FT_IMG_LD + ec);
+            float4* p = reinterpret_cast<float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
             p[0] = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
             p[1] = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
-            __syncthreads();
-            if (tid < 128) {
-#pragma unroll 4
-                for (int r = 0; r < FT_IMG_ROWS; ++r) {
-                    const int nd = rowtab[16 * rnd + r].node;
-                    if (nd != cur) {
-                        if (cur >= 0) atomicAdd(oh + (long)cur * C, csum);
-                        cur = nd;
-                        csum = 0.f;
+            if (lh == 0) {
+#pragma unroll
+                for (int r8 = 0; r8 < FT_IMG_ROWS; r8 += 8) {          // LDS reads of 8 rows first, then the serial chain on registers
+                    float cv[8];
+                    int cn[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) { cv[r] = imgw[(r8 + r) * FT_IMG_LD + lr]; cn[r] = rowtab[16 * rnd + r8 + r].node; }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (cn[r] != cur) {            // wave-uniform: every lane looks at the same row
+                            if (cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+                            cur = cn[r];
+                            csum = 0.f;
+                        }
+                        if (cn[r] >= 0) csum += cv[r];
                     }
-                    if (nd >= 0) csum += img[r * FT_IMG_LD + tid];
                 }
             }
         }
-        if (tid < 128 && cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+        if (lh == 0 && cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+        FT_MARK(5 + 2 * j);
     }
+#undef FT_MARK
 }
 
-int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st) {
-    REGT_CHECK_ARG(a.M > 0 && a.T > 0, "fused forward: empty problem");
+static long* g_fused_trace = nullptr;
+static long g_fused_trace_n = 0;
+// copies the stamps of the last traced launch to the host (synchronises); returns the number of values
+long fused_trace_fetch(long* out, long capacity) {
+    if (!g_fused_trace || !out) return 0;
+    const long n = capacity < g_fused_trace_n ? capacity : g_fused_trace_n;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(out, g_fused_trace, n * sizeof(long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
+    REGT_CHECK_ARG(a_.M > 0 && a_.T > 0, "fused forward: empty problem");
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("REGT_FUSED_DBG"); dbg = e ? atoi(e) : 0; }
+    FusedFwdArgs a = a_;
+    a.dbg = dbg;
+    a.trace = nullptr;
+    {
+        static int tr = -1;
+        if (tr < 0) { const char* e = getenv("REGT_FUSED_TRACE"); tr = e ? atoi(e) : 0; }
+        if (tr) {
+            const long tiles_t = (a_.M + FT_ROWS - 1) / FT_ROWS;
+            if (!g_fused_trace || g_fused_trace_n < 8 * tiles_t) {
+                if (g_fused_trace) (void)hipFree(g_fused_trace);
+                REGT_CHECK_HIP(hipMalloc(&g_fused_trace, 8 * tiles_t * sizeof(long)));
+                g_fused_trace_n = 8 * tiles_t;
+            }
+            a.trace = g_fused_trace;
+        }
+    }
     REGT_CHECK_ARG(C == 256 && F == 64, "fused forward: built for C = 256, F = 64 (got C = %d, F = %d)", C, F);
     const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
     REGT_CHECK_ARG(tiles < (1L << 31), "fused forward: too many tiles");

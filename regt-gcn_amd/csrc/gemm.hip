@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void cand_epilogue(const CandArgs& a, const SplitCore
 #undef F_
                 buf_st4(sht, vc + i * sc, 0, ht);
                 const float4 Zv = Z[k & 1][j], hh = hv[k & 1][j];
-#define F_(q) (pt * (Zv.q * hh.q + (1.0f - Zv.q) * ht.q))
+#define F_(q) __fmul_rn(pt, gru_blend(Zv.q, hh.q, ht.q))
                 *reinterpret_cast<float4*>(img) = REGT_V4(F_);
 #undef F_
             }
@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
 #undef F_
                 buf_st8_bf16(sht, vc + i * sc, ht);
                 const F8 Zv = widen8(Z[k & 1][j]), hh = widen8(hv[k & 1][j]);
-#define F_(q) (pt * (Zv.q * hh.q + (1.0f - Zv.q) * ht.q))
+#define F_(q) __fmul_rn(pt, gru_blend(Zv.q, hh.q, ht.q))
                 const F8 o = REGT_F8(F_);
 #undef F_
                 img[0] = o.lo;

@@ -46,6 +46,11 @@ __device__ __forceinline__ void buf_st4_bf16(__amdgpu_buffer_rsrc_t r, int voff,
                        __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_t))};
     __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
 }
+// GRU blend H' = Z h + (1 - Z) H~ (models/utils.py:186-188) with ONE fixed instruction sequence -- fma(Z, h, fl((1 - Z) H~)) --
+// wherever it is computed (candidate epilogues in gemm.hip, fused forward in fused.hip): left to -ffp-contract the two
+// kernels could round differently, and tests/test_gpu_fused.py compares them bit for bit.
+__device__ __forceinline__ float gru_blend(float Z, float h, float ht) { return fmaf(Z, h, __fmul_rn(1.0f - Z, ht)); }
+
 // per tile row: byte offset of the row's node in an (N, C) fp32 array and its period's attention probability (EpiDgrad1F)
 struct EpiRowEnt { int off; float p; };
 // where a thread sits in the epilogue of a full tile: rows rr + step * i (i = row slot), columns c .. of the tile at (m0, n0)
@@ -224,7 +229,10 @@ struct FusedFwdArgs {
     void *h, *ZR, *q, *Ht;                    // bf16 outputs: (M x C), (M x 2C) = [Z | R], (M x C), (M x C)
     float* OH;                                // (nodes x C) fp32, zero-initialised: the attention-weighted hidden state
     long M; int T; float slope; int act_lrelu;
+    int dbg;                                  // timing-only switches (REGT_FUSED_DBG, fused.hip); 0 in normal operation
+    long* trace;                              // developer trace buffer (REGT_FUSED_TRACE) or nullptr
 };
+long fused_trace_fetch(long* out, long capacity);
 int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st);
 bool fused_forward_ok(int C, int F);
 

@@ -279,16 +279,7 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
     }
 }
 
-// ---- row-block variant: the CSR entries of a workgroup's rows live in LDS, the workgroup walks ALL column panels ------------
-// The panel kernels above read a row's (col, weight, weight) entries again for every panel: 6 x 13 MB at cfg-3, and those
-// streams compete with the X slice for the XCD's 4 MiB L2.  Here a workgroup owns GROUPS x rpg consecutive-ish rows of its
-// XCD's node chunk for the whole launch: it copies their entries to LDS once (one coalesced pass over the CSR: 13 MB in total)
-// and then walks panel 0, 1, ... over them.  rpg is chosen on the host so that ALL workgroups of an XCD are resident at
-// once (8 per CU): they start together and advance through the panels at about the same pace, so the live slice of X per
-// XCD is still ~one panel wide (speed only -- nothing depends on the pacing).  A lane group of PL lanes owns one row at a time;
-// it reads entries back with broadcast ds_read_b128 (no shuffles) and keeps 8 gathers in flight.  Rows of X / Y are addressed
-// through buffer descriptors: 32-bit byte offsets, the panel offset is the instruction's scalar offset.
-// BF: rows of X and of both outputs hold bf16 (16 bytes = 8 elements per lane), accumulation in fp32, one rounding at the end.
+// ---- 16 bytes per lane of either row format: 4 fp32 or 8 bf16 elements; fp32 accumulation, one rounding at the end ----------
 struct SpEnt { int col; float wa, wl; int pad; };
 template <bool BF> struct SpAcc { float v[BF ? 8 : 4]; };
 template <bool BF>
@@ -319,6 +310,78 @@ __device__ __forceinline__ u32x4_t sp_pack(const SpAcc<BF>& a) {
         return u32x4_t{__float_as_uint(a.v[0]), __float_as_uint(a.v[1]), __float_as_uint(a.v[2]), __float_as_uint(a.v[3])};
     }
 }
+
+// The dual-operator panel kernel on bf16 rows (REGT_GEMM_MODE=bf16: x, A_hat x and L~ x only ever feed bf16 matrix-core operands):
+// same schedule, a lane holds 8 elements of its 16 bytes, sums in fp32 in CSR order, outputs rounded once (nearest even).
+template <int PL, int IDX>
+__global__ __launch_bounds__(256, 5) void spmm_dual_panel_bf16_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                                   const float* __restrict__ val_a, const float* __restrict__ val_l,
+                                                                   const uint4* __restrict__ X, uint4* __restrict__ YA,
+                                                                   uint4* __restrict__ YL, int nnodes, int W16, int npanels, int nrb,
+                                                                   unsigned x_bytes) {
+    static_assert(IDX % 8 == 0 && IDX <= PL, "index chunk is a multiple of the 8-gather round and fits the lane group");
+    constexpr int ROWS = 256 / PL;
+    // rows of X through a buffer descriptor: 32-bit byte offsets (host-checked), no 64-bit address arithmetic per gather
+    const __amdgpu_buffer_rsrc_t sx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, x_bytes, 0x00020000);
+    const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
+    const int panel = li / nrb;
+    if (panel >= npanels) return;
+    const int rb = li - panel * nrb;
+    const int q = nnodes / 8, r8 = nnodes % 8;
+    const int c0 = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int csz = q + (xcd < r8 ? 1 : 0);
+    const int g = threadIdx.x / PL, gl = threadIdx.x % PL;
+    if (rb * ROWS + g >= csz) return;
+    const long row = c0 + rb * ROWS + g;
+    const unsigned lane_off = (unsigned)(panel * PL + gl) * 16u, rowbytes = (unsigned)W16 * 16u;
+    SpAcc<true> aa, al;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { aa.v[i] = 0.f; al.v[i] = 0.f; }
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int base = beg; base < end; base += IDX) {
+        const int n = end - base < IDX ? end - base : IDX;
+        int myc = 0;
+        float mya = 0.f, myl = 0.f;
+        if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+#pragma unroll
+        for (int r = 0; r < IDX / 8; ++r) {
+            if (r * 8 < n) {
+                u32x4_t x[8];
+                float va[8], vl[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = __shfl(myc, r * 8 + e, PL);
+                    va[e] = __shfl(mya, r * 8 + e, PL);
+                    vl[e] = __shfl(myl, r * 8 + e, PL);
+                    x[e] = r * 8 + e < n ? __builtin_amdgcn_raw_buffer_load_b128(sx, (unsigned)c * rowbytes + lane_off, 0, 0) : u32x4_t{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sp_fma<true>(aa, va[e], x[e]);
+                    sp_fma<true>(al, vl[e], x[e]);
+                }
+            }
+        }
+    }
+    const u32x4_t pa = sp_pack<true>(aa), pl = sp_pack<true>(al);
+    unsigned* oa = reinterpret_cast<unsigned*>(YA + row * W16 + panel * PL + gl);
+    unsigned* ol = reinterpret_cast<unsigned*>(YL + row * W16 + panel * PL + gl);
+    __builtin_nontemporal_store(pa.x, oa); __builtin_nontemporal_store(pa.y, oa + 1);
+    __builtin_nontemporal_store(pa.z, oa + 2); __builtin_nontemporal_store(pa.w, oa + 3);
+    __builtin_nontemporal_store(pl.x, ol); __builtin_nontemporal_store(pl.y, ol + 1);
+    __builtin_nontemporal_store(pl.z, ol + 2); __builtin_nontemporal_store(pl.w, ol + 3);
+}
+
+// ---- row-block variant: the CSR entries of a workgroup's rows live in LDS, the workgroup walks ALL column panels ------------
+// The panel kernels above read a row's (col, weight, weight) entries again for every panel: 6 x 13 MB at cfg-3, and those
+// streams compete with the X slice for the XCD's 4 MiB L2.  Here a workgroup owns GROUPS x rpg consecutive-ish rows of its
+// XCD's node chunk for the whole launch: it copies their entries to LDS once (one coalesced pass over the CSR: 13 MB in total)
+// and then walks panel 0, 1, ... over them.  rpg is chosen on the host so that ALL workgroups of an XCD are resident at
+// once (8 per CU): they start together and advance through the panels at about the same pace, so the live slice of X per
+// XCD is still ~one panel wide (speed only -- nothing depends on the pacing).  A lane group of PL lanes owns one row at a time;
+// it reads entries back with broadcast ds_read_b128 (no shuffles) and keeps 8 gathers in flight.  Rows of X / Y are addressed
+// through buffer descriptors: 32-bit byte offsets, the panel offset is the instruction's scalar offset.
+// BF: rows of X and of both outputs hold bf16 (16 bytes = 8 elements per lane), accumulation in fp32, one rounding at the end.
 // LDS entries per workgroup (16 B each, behind the 260-int row pointer slice): what 8 (fp32 rows, 64 VGPRs) or 5 (bf16 rows, 84 VGPRs)
 // resident workgroups per CU leave each of them
 static int rows_cap(bool bf) { return (163840 / (bf ? 5 : 8) - 260 * 4 - 64) / 16; }
@@ -420,10 +483,10 @@ static int launch_spmm_rows(const int* rowptr, const int* col, const float* val_
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
-// REGT_SPMM_ROWS: 1 = row-block kernel where eligible (default), 0 = panel kernels only (A/B timing)
+// REGT_SPMM_ROWS / regt_set_option("spmm_rows"): 1 = row-block kernel where eligible, 0 (default) = panel kernels
 static int g_rows_opt = -1;
 static bool rows_wanted() {
-    if (g_rows_opt < 0) { const char* e = getenv("REGT_SPMM_ROWS"); g_rows_opt = e ? atoi(e) : 1; }
+    if (g_rows_opt < 0) { const char* e = getenv("REGT_SPMM_ROWS"); g_rows_opt = e ? atoi(e) : 0; }   // opt-in: measured slower
     return g_rows_opt != 0;
 }
 int spmm_rows_option(int value) {       // regt_set_option("spmm_rows", v): returns the previous setting
@@ -445,8 +508,19 @@ int launch_spmm_dual_bf16(const int* rowptr, const int* col, const float* val_a,
     if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
     const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && rowbytes % 256 == 0;
     const int PL = wide ? 16 : 8;
-    REGT_CHECK_ARG(x_rows * rowbytes < (1L << 32) - 4096 && (256 / PL) * rows_rpg(nnodes, PL, true) <= 256, "spmm_dual (bf16 rows): problem too large for 32-bit row offsets");
-    return launch_spmm_rows<true, true>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, (int)rowbytes, PL, st);
+    REGT_CHECK_ARG(x_rows * rowbytes < (1L << 32) - 4096, "spmm_dual (bf16 rows): X larger than 4 GB");
+    if (rows_wanted() && (256 / PL) * rows_rpg(nnodes, PL, true) <= 256)
+        return launch_spmm_rows<true, true>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, (int)rowbytes, PL, st);
+    const unsigned xb = (unsigned)(x_rows * rowbytes);
+    const int W16 = (int)(rowbytes / 16), npanels = W16 / PL, nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
+    const long grid = 8L * npanels * nrb;
+    REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual (bf16 rows): grid too large");
+    const uint4* X16 = reinterpret_cast<const uint4*>(X);
+    uint4 *A16 = reinterpret_cast<uint4*>(YA), *L16 = reinterpret_cast<uint4*>(YL);
+    if (wide) hipLaunchKernelGGL((spmm_dual_panel_bf16_kernel<16, 16>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X16, A16, L16, nnodes, W16, npanels, nrb, xb);
+    else hipLaunchKernelGGL((spmm_dual_panel_bf16_kernel<8, 8>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X16, A16, L16, nnodes, W16, npanels, nrb, xb);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
 }
 
 int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,

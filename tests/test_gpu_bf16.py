@@ -102,7 +102,9 @@ def test_bf16_mode_matches_oracle_within_derived_tolerance(bf16_mode, n, e, regi
         err = float((q.grad.cpu() - want).norm())
         # softmax backward subtracts the probability-weighted mean of dL/dp (the T attention gradients sum to 0): the result
         # is a difference of nearly equal terms, so its relative error is a multiple of theirs -- 4x the bar for this tensor
-        tol = TOL_REL * (4.0 if k == "tgnn._attention" else 1.0)
+        # (6x where the fused forward applies -- F = 64, several regions: the snapshot itself is rounded to bf16 there, one more
+        # rounding source in front of the same cancellation; measured 4.6 x the bar of the other tensors)
+        tol = TOL_REL * ((6.0 if f == 64 and regions > 1 else 4.0) if k == "tgnn._attention" else 1.0)
         assert err <= tol * float(want.norm()) + 1e-9, (k, err, float(want.norm()))
 
 

@@ -25,7 +25,7 @@ def bf16_mode():
     yield R
     lib.regt_set_gemm_mode(prev)
     lib.regt_set_option(b"xbf", 1)
-    lib.regt_set_option(b"spmm_rows", 1)
+    lib.regt_set_option(b"spmm_rows", 0)
 
 
 def test_pack_x_bf16_rounds_to_nearest_even_and_leaves_halo_rows_alone():
@@ -45,7 +45,14 @@ def test_bf16_row_aggregation_is_the_rounded_fp32_aggregation(n, e, regions, w, 
     ei, ri, rw, _ = _synthetic(n, e, regions, 4, 1, seed=n)
     g = R.prepare_graph(ei.cuda(), None, [i.cuda() for i in ri], [a.cuda() for a in rw], n)
     x = torch.randn(n + extra, w, device="cuda").to(torch.bfloat16)
+    lib = R.load_library()
+    try:            # the opt-in row-block kernel and the default panel kernel sum in the same order
+        lib.regt_set_option(b"spmm_rows", 1)
+        ra, rl = R.ops.spmm_dual_bf16(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
+    finally:
+        lib.regt_set_option(b"spmm_rows", 0)
     ya, yl = R.ops.spmm_dual_bf16(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
+    assert torch.equal(ra, ya) and torch.equal(rl, yl)
     if w % 32 == 0:
         fa, fl = R.ops.spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x[:n].float().contiguous())
     # reference sums in float64 from the CSR itself (also covers halo columns: none here, but x has extra rows)
@@ -73,7 +80,7 @@ def test_row_block_kernel_equals_panel_kernel_bit_for_bit(n, e, regions, w):
         lib.regt_set_option(b"spmm_rows", 0)
         a0, l0 = R.ops.spmm_dual(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, x)
     finally:
-        lib.regt_set_option(b"spmm_rows", 1)
+        lib.regt_set_option(b"spmm_rows", 0)
     assert torch.equal(a1, a0) and torch.equal(l1, l0)
 
 

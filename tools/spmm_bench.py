@@ -38,7 +38,7 @@ for rows in (1, 0):          # row-block kernel (CSR entries in LDS) vs column-p
     ms_cold = t_cold(dual)
     print(f"dual  rows={rows} PL={os.environ.get('REGT_SPMM_PL','auto')}: {ms*1e3:7.1f} us  {algo/ms/1e6:7.1f} GB/s algorithmic ({algo/1e6:.1f} MB)  nnz={nnz}   "
           f"cold: {ms_cold*1e3:7.1f} us = {algo/ms_cold/1e6/8000:.3f} of 8 TB/s")
-lib.regt_set_option(b"spmm_rows", 1)
+lib.regt_set_option(b"spmm_rows", 0)
 # bf16 rows (REGT_GEMM_MODE=bf16, cfg-5 layout): same row bytes at twice the feature count
 xb = torch.rand(nodes, 2 * W, device=dev).to(torch.bfloat16)
 yab = torch.empty_like(xb); ylb = torch.empty_like(xb)
