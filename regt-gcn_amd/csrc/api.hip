@@ -181,7 +181,9 @@ bool weights_frag(const regt_dims& d) {
            reg_slabs <= 64 && (2L * d.C + d.F) / 32 <= 64;
 }
 bool xbf_ok(const regt_dims& d, const regt_graph& g, bool h_ext, int x_rows, bool packed_fp32) {
-    return xbf_wanted() && weights_frag(d) && d.regional && d.R > 1 && !g.overlap && !h_ext && g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l &&
+    // (fragment-order weights as in weights_frag(), without its bound on the regional GEMM's slab table: the fused kernel has none)
+    const bool frag = bf16_intermediates(d) && d.F % 32 == 0 && d.C % 128 == 0 && !gemm_desc_table_forced() && !fp32_core_wide();
+    return xbf_wanted() && frag && d.regional && d.R > 1 && !g.overlap && !h_ext && g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l &&
            g.chunk_tab && g.chunk_region && g.n_chunks > 0 &&
            fused_forward_ok(d.C, d.F) && ((long)d.T * d.F) % 64 == 0 && (!packed_fp32 || x_rows <= 2 * d.N) &&
            (long)(x_rows > d.N ? x_rows : d.N) * d.T * d.F * 2 < (1L << 32) - 4096;
@@ -551,6 +553,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
 // Weight-gradient slabs and their reductions inside one backward pass: every wgrad gets its own slab region and its
 // reduction is only recorded; flush() runs all recorded reductions in ONE launch.  A region request that does not fit
 // flushes first and starts over at the base of the slab (stream order keeps that safe).
+static int side_join(hipStream_t st);      // work forked to the library's side stream completes before any slab is reduced
 struct ReduceQueue {
     float* base;
     long capacity, used = 0;
@@ -571,6 +574,7 @@ struct ReduceQueue {
         return REGT_OK;
     }
     int flush_keep_slab() {
+        TRY(side_join(st));
         if (batch.n) {
             PROF("wgrad_reduce", st);
             TRY(launch_wgrad_reduce_multi(batch, st));
@@ -584,6 +588,38 @@ struct ReduceQueue {
         return REGT_OK;
     }
 };
+
+// ---- side stream for work off the critical path of a backward pass -----------------------------------------------------------------
+// The two weight gradients of the head (a few hundred MB of reads, grids far smaller than the chip) depend only on the head's own
+// data gradient; the cell backward that follows on the launch stream does not need them.  They run on a library-owned stream,
+// forked behind the kernel that produces d1 and joined in front of the slab reduction: 0.18 ms of the cfg-5 shard step (and
+// of a one-region-per-GPU shard, where such fixed costs are what strong scaling loses) overlap the cell backward instead of
+// preceding it.  REGT_SIDE_STREAM=0 keeps everything on the launch stream; captured launch sequences (REGT_HIPGRAPH) do too.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int enabled = -1;
+    bool forked = false;
+};
+static SideStream g_side;
+static hipStream_t side_fork(hipStream_t st) {       // returns the stream to launch on (st itself when the side stream is off)
+    if (g_side.enabled < 0) { const char* e = getenv("REGT_SIDE_STREAM"); g_side.enabled = e ? atoi(e) : 1; }
+    if (!g_side.enabled || g_graph_mode > 0) return st;
+    if (!g_side.s) {
+        if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) { g_side.enabled = 0; g_side.s = nullptr; (void)hipGetLastError(); return st; }
+    }
+    if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork, 0) != hipSuccess) { (void)hipGetLastError(); return st; }
+    g_side.forked = true;
+    return g_side.s;
+}
+static int side_join(hipStream_t st) {
+    if (!g_side.forked) return REGT_OK;
+    g_side.forked = false;
+    REGT_CHECK_HIP(hipEventRecord(g_side.join, g_side.s));
+    REGT_CHECK_HIP(hipStreamWaitEvent(st, g_side.join, 0));
+    return REGT_OK;
+}
 
 int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu,
                long M, int kchunk, int nchunks, float* out, long ldo, float* colsum, hipStream_t st, int p_bf16 = 0, int q_bf16 = 0) {
@@ -611,17 +647,21 @@ int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr
     if (skinny) {
         float* slab = nullptr;
         TRY(rq.take((long)nchunks_head * ((long)O * H1 + O), &slab));
+        {   // d1 first: the weight gradients leave the critical path behind it (side stream)
+            PROF("head_bwd", st);
+            TRY(launch_head2_bwd(dpred, p.head2_w, y1, d1, N, H1, O, st));
+        }
+        hipStream_t ss = side_fork(st);
         {
-            PROF("wgrad_head2", st);
-            TRY(launch_head2_wgrad(dpred, y1, slab, N, H1, O, kchunk_head, nchunks_head, 1, st));
+            PROF("wgrad_head2", ss);
+            TRY(launch_head2_wgrad(dpred, y1, slab, N, H1, O, kchunk_head, nchunks_head, 1, ss));
         }
         WgradReduceArgs r{};
         r.slab = slab; r.nchunks = nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
         r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
         r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
         TRY(rq.push(r));
-        PROF("head_bwd", st);
-        TRY(launch_head2_bwd(dpred, p.head2_w, y1, d1, N, H1, O, st));
+        TRY(wgrad_full(rq, "wgrad_head1", d1, H1, H1, hidden, C, C, 1, N, kchunk_head, nchunks_head, gr.head1_w, C, gr.head1_b, ss));
     } else {
         TRY(wgrad_full(rq, "wgrad_head2", dpred, O, O, y1, H1, H1, 0, N, kchunk_head, nchunks_head, gr.head2_w, H1, gr.head2_b, st));
         // d1 = (dpred A2) * (y1 > 0)
@@ -632,8 +672,8 @@ int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr
         EpiMaskAdd e{d1, H1, y1, H1, nullptr, 0};
         PROF("head_bwd", st);
         TRY(launch_gemm_mask_add(S, N, H1, e, st));
+        TRY(wgrad_full(rq, "wgrad_head1", d1, H1, H1, hidden, C, C, 1, N, kchunk_head, nchunks_head, gr.head1_w, C, gr.head1_b, st));
     }
-    TRY(wgrad_full(rq, "wgrad_head1", d1, H1, H1, hidden, C, C, 1, N, kchunk_head, nchunks_head, gr.head1_w, C, gr.head1_b, st));
     {   // dOH = (d1 A1) * (hidden > 0) + dhidden
         GemmSegs S{};
         S.nseg = 1;
@@ -739,6 +779,9 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(rq.push(r));
         }
     }
+    // (One launch per pair with a two-part right-hand side [q | A_hat x] / [h | A_hat x] -- so that dhp and dzp|drp are read
+    // once -- was measured and is slower: 1.86 vs 1.44 ms for the four at the cfg-5 shard; the third, half-empty column tile and
+    // the doubled load instructions of the two-descriptor staging cost more than the second pass over the left operand.)
     TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st, ibf, xbf));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
@@ -806,7 +849,9 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             add_task(b, gr.gate_w[k], 2L * C, 1, 0, C, C, 1, nullptr, 0,
                      {term(dG, F, 1, 0, p.conv_lin_w[k], 1, F, 0, F), term(dc, 1, 0, 0, p.conv_bias[k], 0, 1, 0, 1)});
             // dV_k = U_k[:, :C]^T dG_k ; dbeta_k = U_k[:, :C]^T dc_k
-            add_task(b, gr.conv_lin_w[k], F, 1, 0, C, F, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dG, F, 1, 0, C)});
+            // (stated transposed -- output "rows" j, "columns" i -- so that consecutive lanes walk the CONTIGUOUS index i of the
+            // left factor U_k[k, i]; as (i, j) every k-step of a lane group touched lines 2C floats apart)
+            add_task(b, gr.conv_lin_w[k], 1, F, 0, F, C, 1, nullptr, 0, {term(dG, 1, F, 0, p.gate_w[k], 2L * C, 1, 0, C)});
             add_task(b, gr.conv_bias[k], 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, C)});
         }
         if (d.regional)      // G0 = dA0 W0^T + db' b_c^T: what EVERY block of d tgnn.linear.weight receives (A0 and b' sum over all regions)
@@ -828,9 +873,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             if (lo > 0) add_task(b, gr.region_w, RC, 1, C, C, C, lo, L.G0, C, {}, 1);
             if (hi < R) add_task(b, gr.region_w + (long)hi * C, RC, 1, C, C, C, R - hi, L.G0, C, {}, 1);
             // dW0 = S^T dA0 ; dW1 = sum_{owned r} Wl_r^T dA_r ; db_c = S^T db' ; db_l = db'
-            add_task(b, gr.cheb_w0, F, 1, 0, C, F, 1, nullptr, 0, {term(L.S, 1, C, 0, L.dA0, F, 1, 0, C)});
-            add_task(b, gr.cheb_w1, F, 1, 0, C, F, 1, nullptr, 0,
-                     {term(p.region_w + (long)lo * C, 1, RC, C, L.dAall + (long)lo * C * F, F, 1, (long)C * F, C, hi - lo, 1)});
+            // (both stated transposed, see dV_k above: tgnn.linear.weight rows are R*C floats apart)
+            add_task(b, gr.cheb_w0, 1, F, 0, F, C, 1, nullptr, 0, {term(L.dA0, 1, F, 0, L.S, C, 1, 0, C)});
+            add_task(b, gr.cheb_w1, 1, F, 0, F, C, 1, nullptr, 0,
+                     {term(L.dAall + (long)lo * C * F, 1, F, (long)C * F, p.region_w + (long)lo * C, RC, 1, C, C, hi - lo, 1)});
             add_task(b, gr.cheb_bias, 1, 0, 0, C, 1, 1, nullptr, 0, {term(L.S, 1, C, 0, L.dbprime, 1, 0, 0, C)});
             add_task(b, gr.region_b, 1, 0, 0, C, 1, 1, L.dbprime, 1, {});
         }

@@ -2299,8 +2299,9 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.Nout > 0 && a.Nin > 0 && a.nchunks > 0, "wgrad: empty problem");
     // a two-part right-hand side runs on the skinny fp32 kernel, except under the bf16 arithmetic with Nin <= 128 (one
     // column tile of the bf16-pipe kernel: at F = 64 the fused dA0 / dA_r gradient is fp32-MFMA-bound on the skinny kernel)
-    const bool q2_split = a.Q2 && gemm_mode() == 2 && a.Nin > 32 && a.Nin <= 128 && !a.q_relu && a.nin_split % (a.q_bf16 ? 8 : 4) == 0 && !fp32_core_wide() &&
-                          (!a.q_bf16 || a.ldq2 % 8 == 0);
+    // (any width when both parts are stored as bf16: the fused [q | A_hat x] / [h | A_hat x] gradients of the bf16-row layout)
+    const bool q2_split = a.Q2 && gemm_mode() == 2 && a.Nin > 32 && (a.Nin <= 128 || a.q_bf16) && !a.q_relu && a.nin_split % (a.q_bf16 ? 8 : 4) == 0 &&
+                          !fp32_core_wide() && (!a.q_bf16 || a.ldq2 % 8 == 0);
     const bool wide = a.Nin > 32 && (!a.Q2 || q2_split);
     const int bnw = wide ? 128 : 32;
     long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
