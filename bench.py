@@ -49,8 +49,8 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s is the measured ac
 # HBM bytes per launch come from rocprofv3 PMC passes of this same command (tools/bench_pmc.sh -> tools/pmc_summary.py):
 # 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B/lane streaming reads -- MI355X_MICROARCH.md, HBM section;
 # calibrated on cell_bwd, whose 3.7 GB of float4 reads show as 2.08e6 KB) + WRITE_SIZE, both in KB in the summary.
-PMC_SUMMARIES = {("cfg3", 0): "profiles/r02_cfg3_pmc_hbm_summary.txt",
-                 ("cfg5shard", 2): "profiles/r02_cfg5shard_pmc_hbm_summary.txt"}
+PMC_SUMMARIES = {("cfg3", 0): "profiles/r03_cfg3_pmc_hbm_summary.txt",
+                 ("cfg5shard", 2): "profiles/r03_cfg5shard_pmc_hbm_summary.txt"}
 
 WORKLOADS = {
     # per-GPU shape: nodes, edges, regions, F, T, O; GEMM arithmetic (regt_set_gemm_mode) and the dtype it computes in
@@ -82,6 +82,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3-split / bf16 measurements")
     ap.add_argument("--no-tpims-leg", action="store_true", help="skip the secondary TPIMS-scale (configs[1]) measurement")
+    ap.add_argument("--no-cfg5-leg", action="store_true",
+                    help="skip the secondary cfg5shard leg (one rank's share of BASELINE configs[4], bf16 arithmetic, run as a child process)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-stage HIP events")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     return ap.parse_args()
@@ -208,7 +210,28 @@ def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):
                         "launch-latency-bound"}
 
 
+def cfg5shard_leg(args):
+    """BASELINE.json configs[4] on the hardware the driver has: rank 0's share of the 8-GPU job (125 000 own nodes + halo rows,
+    8 of 64 regions, F = 64, bf16 GEMM operands) as a child process of this bench -- its own library state, its own JSON line
+    with the roofline of ITS dominant kernel.  Secondary leg: never the headline value."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg5shard", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--no-split-leg", "--no-tpims-leg"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        leg = json.loads(line[-1])
+        leg.pop("stages", None)          # the per-stage table of the leg: `python bench.py --workload cfg5shard` prints it
+        return leg
+    except Exception as e:               # a secondary leg must never take the headline line down
+        return {"error": repr(e)}
+
+
 def stage_flops(stage, M, C, F):
+    if stage == "fused_forward":        # regional embedding + gates + candidate in one kernel (bf16 arithmetic, csrc/fused.hip)
+        return 2.0 * M * (C * 2 * F + 2 * C * (C + F) + C * (C + F))
     return {
         "gemm_gates": 2.0 * M * 2 * C * (C + F), "gemm_candidate": 2.0 * M * C * (C + F),
         "gemm_regional": 2.0 * M * C * 2 * F, "dgrad_candidate": 2.0 * M * C * C, "dgrad_gates": 2.0 * M * C * 2 * C,
@@ -217,20 +240,23 @@ def stage_flops(stage, M, C, F):
     }.get(stage)
 
 
-def stage_bytes(stage, M, C, F, mode=0):
+def stage_bytes(stage, M, C, F, mode=0, xbf=False):
     """Algorithmic HBM bytes of one launch: every activation operand read once, every result written once; weights and
     per-node vectors are negligible.  fp32 storage (4 B) except under GEMM mode 2 (bf16), where the M x C activations
-    (h, [Z|R], q, H~, dh, dhp, dzp|drp) are stored as bf16 (2 B); x, A_hat x, L~ x stay fp32.  DESIGN.md section 5."""
+    (h, [Z|R], q, H~, dh, dhp, dzp|drp) are stored as bf16 (2 B); x, A_hat x, L~ x are fp32 rows unless ``xbf`` (the bf16-row
+    layout of the fused forward).  DESIGN.md section 5."""
     a = 2.0 if mode == 2 else 4.0       # bytes per element of an M x C activation
+    x = 2.0 if xbf else 4.0             # bytes per element of x, A_hat x, L~ x
     per_row = {
-        "gemm_gates": a * C + 4.0 * F + a * 2 * C + a * C,          # read h, A_hat x; write [Z|R], q
-        "gemm_candidate": a * C + 4.0 * F + a * C + a * C + a * C,  # read q, A_hat x, Z, h; write H~
-        "gemm_regional": 4.0 * 2 * F + a * C,                       # read x, L~ x; write h
+        "gemm_gates": a * C + x * F + a * 2 * C + a * C,            # read h, A_hat x; write [Z|R], q
+        "gemm_candidate": a * C + x * F + a * C + a * C + a * C,    # read q, A_hat x, Z, h; write H~
+        "gemm_regional": x * 2 * F + a * C,                         # read x, L~ x; write h
+        "fused_forward": x * 3 * F + a * 5 * C,                     # read x, L~ x, A_hat x; write h, [Z|R], q, H~ -- nothing read back
         "cell_bwd": a * 3 * C + a * 2 * C,                          # read Z, h, H~; write dhp, dzp
         "dgrad_candidate": a * (C + C + 2 * C) + a * 2 * C,         # read dhp, h, Z, R; write drp, dh
         "dgrad_gates": a * (2 * C + C + C) + a * C,                 # read dzp|drp, dh, h; write ds
-        "wgrad_Uzr": a * 3 * C, "wgrad_Uh": a * 2 * C, "wgrad_Gzr": a * 2 * C + 4.0 * F, "wgrad_Gh": a * C + 4.0 * F,
-        "wgrad_A0_Ar": a * C + 4.0 * 2 * F,
+        "wgrad_Uzr": a * 3 * C, "wgrad_Uh": a * 2 * C, "wgrad_Gzr": a * 2 * C + x * F, "wgrad_Gh": a * C + x * F,
+        "wgrad_A0_Ar": a * C + x * 2 * F,
     }.get(stage)
     return None if per_row is None else M * per_row
 
@@ -247,6 +273,8 @@ def stage_kernel(stage, mode):
         if mode == 2:
             pats.insert(0, f"gemm_flat_split8_kernel<regt::{epi}8F, false>")
         return pats
+    if stage == "fused_forward":
+        return ["fused_fwd_kernel"]
     if stage == "gemm_candidate":
         return {0: ["gemm_cand_split_kernel<0>", "gemm_cand_flat_kernel<regt::FastCore"],
                 1: ["gemm_cand_split_kernel<3>", "gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
@@ -256,7 +284,7 @@ def stage_kernel(stage, mode):
     if stage == "cell_bwd":
         return ["cell_bwd8_kernel", "cell_bwd_kernel"] if mode == 2 else ["cell_bwd_kernel"]
     if stage == "spmm":
-        return ["spmm_dual_panel_kernel"]
+        return ["spmm_dual_panel_bf16_kernel", "spmm_dual_panel_kernel"] if mode == 2 else ["spmm_dual_panel_kernel"]
     return None
 
 
@@ -353,6 +381,9 @@ def main():
     ys = [y.to(dev) for _, y in snaps]
     del snaps
     pipe = None
+    # bf16 arithmetic at the shape the fused forward covers: x, A_hat x, L~ x are bf16 rows (a region shard packs and exchanges
+    # its rows as bf16)
+    rows_bf16 = mode == 2 and F == 64 and regions > 1 and os.environ.get("REGT_XBF", "1") != "0"
     if world == 1 and not force_shard and not shard_of_8:
         graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index],
                                 [t.to(dev) for t in g.region_attr], n_local)
@@ -362,8 +393,6 @@ def main():
         shard = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, gnodes, owner_bounds, region_owner,
                                    rank, vworld, dev)
         graph = shard.graph
-        # bf16 arithmetic at the shape the fused forward covers: the rank packs (and exchanges) its rows as bf16
-        rows_bf16 = mode == 2 and F == 64 and os.environ.get("REGT_XBF", "1") != "0"
         if shard_of_8:          # no peers: own rows packed once per snapshot, halo rows = random data (input values only)
             ext = []
             for x in xs:
@@ -506,14 +535,14 @@ def main():
                 e = {"launches": c, "avg_ms": ms / c}
                 if stage_flops(k, M, C, F):
                     e["tflops"] = stage_flops(k, M, C, F) / (ms / c * 1e-3) / 1e12
-                if stage_bytes(k, M, C, F, mode):
-                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F, mode) / (ms / c * 1e-3) / 1e9
+                if stage_bytes(k, M, C, F, mode, rows_bf16):
+                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F, mode, rows_bf16) / (ms / c * 1e-3) / 1e9
                 per[k] = e
             mfma = [(ms, k) for k, (c, ms) in stages.items() if stage_flops(k, M, C, F)]
             tot_ms, dom = max(mfma)
             cnt = stages[dom][0]
             avg_s = tot_ms / cnt * 1e-3
-            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F, mode)
+            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F, mode, rows_bf16)
             tflops, gbs = fl / avg_s / 1e12, by / avg_s / 1e9
             traffic, src = pmc_traffic(args.workload, mode, dom)
             mfma_peak = PEAK_FP32_MATRIX_TFLOPS if mode == 0 else PEAK_BF16_MATRIX_TFLOPS
@@ -538,8 +567,9 @@ def main():
                 dual = graph.m_rowptr is not None and W % 32 == 0
                 nnz = int(graph.m_col.numel()) if dual else int(graph.col.numel())
                 x_rows = n_local if shard is None else shard.topo.x_rows
-                # read X once + CSR entries (col + 1 or 2 weights) + rowptr + write both outputs
-                algo = x_rows * W * 4 + nnz * (12 if dual else 8) + (n_local + 1) * 4 * (1 if dual else 2) + 2 * n_local * W * 4
+                # read X once + CSR entries (col + 1 or 2 weights) + rowptr + write both outputs (2-byte elements in the bf16-row layout)
+                eb = 2 if (rows_bf16 and dual and W % 64 == 0) else 4
+                algo = x_rows * W * eb + nnz * (12 if dual else 8) + (n_local + 1) * 4 * (1 if dual else 2) + 2 * n_local * W * eb
                 gbs = algo / (ms / c * 1e-3) / 1e9
                 tr, src2 = pmc_traffic(args.workload, mode, "spmm") if dual else (None, None)
                 out["roofline_spmm"] = {"kernel": "spmm_dual_panel (A_hat x and L~ x in one gather pass, width T*F)" if dual else "spmm_csr (stacked [A_hat; L~] x, width T*F)", "bound": "hbm", "achieved": gbs,
@@ -557,6 +587,8 @@ def main():
                                 + ("; passes the same 1e-5 parity suite" if m2 == 1 else "; reduced precision, tolerance in tests/test_gpu_bf16.py")}
         if tpims is not None:
             out["tpims_configs1"] = tpims
+        if world == 1 and args.workload == "cfg3" and not args.no_cfg5_leg and not force_shard:
+            out["cfg5shard_configs4"] = cfg5shard_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             if shard_of_8:
                 # the reference formulation materialises an (N, R*C) concat: 8.2 GB per period at 125k nodes x 64 regions, so

@@ -78,8 +78,7 @@ struct FusedFwdLds {
     static constexpr int PLANE_B = FT_ROWS * 32;                 // one 16-k block of 64 rows
     static constexpr int OPER_B = (C / 16) * PLANE_B;            // h (or q) of the tile as an A operand
     static constexpr int IMG_OFF = 2 * OPER_B;                   // four wave-private 16-row fp32 images
-    static constexpr int TAB_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
-    static constexpr int BYTES = TAB_OFF + FT_ROWS * (int)sizeof(FRow) + FT_ROWS * 4 + (FT_ROWS + 4) * 4;
+    static constexpr int BYTES = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
 };
 
 template <int C, int F>
@@ -90,14 +89,13 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char flds[];
     char* Hp = flds;
     char* Qp = flds + L::OPER_B;
-    FRow* rowtab = reinterpret_cast<FRow*>(flds + L::TAB_OFF);
-    int* rreg = reinterpret_cast<int*>(rowtab + FT_ROWS);
-    int* ulist = rreg + FT_ROWS;                                 // [0] = number of distinct regions, then the regions
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: fragment addresses go into scalar offsets
     const long m0 = (long)blockIdx.x * FT_ROWS;
     const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
-    const long node0 = m0 / a.T;
+    const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;     // N * T < 2^31 (host-checked): 32-bit row arithmetic
+    const unsigned node0 = mrow0 / uT;
+    const int t0 = (int)(mrow0 - node0 * uT);                    // period of the tile's first row (wave-uniform)
     // developer trace (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of thread 0 at the phase boundaries
 #define FT_MARK(i) do { if (a.trace && tid == 0) a.trace[8L * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
     FT_MARK(0);
@@ -130,34 +128,21 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) b0[0][kb] = f_ldfrag(sA0, lane * 16, (w * KBF + kb) * 1024);
     }
-    if (tid < FT_ROWS) {
-        const long m = m0 + tid;
-        const long node = m / a.T;
-        const int t = (int)(m - node * a.T);
-        const bool ok = tid < nvalid;
-        rowtab[tid] = FRow{ok ? (int)(node - node0) : -1, ok ? a.probs[t] : 0.f};
-        rreg[tid] = ok ? (a.node_region ? a.node_region[node] : 0) : -1;
+    // Row bookkeeping without tables or barriers: every lane looks up the region of ITS two fragment rows (32 mi + lr), every
+    // wave votes on "more than one region in the tile" (rare: a tile that straddles a region boundary), node boundaries and
+    // periods of the rows are wave-uniform scalars (t0 + r) mod T.
+    auto region_of = [&](int r) { return r < nvalid ? (a.node_region ? a.node_region[(mrow0 + (unsigned)r) / uT] : 0) : -1; };
+    const int rg_a = region_of(lr), rg_b = region_of(32 + lr);
+    const int rg0 = __builtin_amdgcn_readfirstlane(rg_a);
+    const bool multi = __ballot((rg_a >= 0 && rg_a != rg0) || (rg_b >= 0 && rg_b != rg0)) != 0;
+    float ptr_[4];                                               // attention probability of the lane's epilogue row of each round
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const unsigned m = mrow0 + 16 * rnd + (lane >> 2);
+        ptr_[rnd] = a.probs[m - (m / uT) * uT];
     }
-    __syncthreads();
-    // distinct regions of the tile's rows, in order of first appearance.  Usually one: wave 0 (one lane per row) votes on
-    // "differs from row 0"; only a tile that really holds several regions pays for the serial scan.
-    const bool multi = tid < FT_ROWS ? __ballot(tid < nvalid && rreg[tid] != rreg[0]) != 0 : false;
-    if (tid == 0 && !multi) { ulist[0] = 1; ulist[1] = rreg[0]; }
-    if (tid == 0 && multi) {
-        int n = 0;
-        for (int r = 0; r < nvalid; ++r) {
-            const int g = rreg[r];
-            bool seen = false;
-            for (int i = 0; i < n; ++i) seen = seen || ulist[1 + i] == g;
-            if (!seen) ulist[1 + n++] = g;
-        }
-        ulist[0] = n;
-    }
-    __syncthreads();
-    const int nuniq = __builtin_amdgcn_readfirstlane(ulist[0]);
-    const int rg0 = __builtin_amdgcn_readfirstlane(ulist[1]);
     {
-        const int o0 = rreg[lr] == rg0 ? afo : 0x7ffffff0, o1 = rreg[32 + lr] == rg0 ? afo + 32 * F * 2 : 0x7ffffff0;
+        const int o0 = rg_a == rg0 ? afo : 0x7ffffff0, o1 = rg_b == rg0 ? afo + 32 * F * 2 : 0x7ffffff0;
         const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) {
@@ -270,11 +255,17 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[0][kb], j ? b1[1][kb] : b0[1][kb], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[1][kb], j ? b1[1][kb] : b0[1][kb], acc[1], 0, 0, 0);
         }
+        // further regions of the tile (rare), in order of first appearance by row: rows of other regions contribute zeros
+        bool done_a = rg_a < 0 || rg_a == rg0, done_b = rg_b < 0 || rg_b == rg0;
 #pragma unroll 1
-        for (int u = 1; u < nuniq; ++u) {       // further regions of the tile (rare): rows of other regions contribute zeros
-            const int rg = __builtin_amdgcn_readfirstlane(ulist[1 + u]);
+        while (multi) {
+            const unsigned long long ma = __ballot(!done_a), mb = __ballot(!done_b);
+            if (!(ma | mb)) break;
+            const int rg = ma ? __builtin_amdgcn_readlane(rg_a, __builtin_ctzll(ma)) : __builtin_amdgcn_readlane(rg_b, __builtin_ctzll(mb));
+            done_a = done_a || rg_a == rg;
+            done_b = done_b || rg_b == rg;
             const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg * a.ar_stride, (long)C * F * 2);
-            const int o0 = rreg[lr] == rg ? afo : 0x7ffffff0, o1 = rreg[32 + lr] == rg ? afo + 32 * F * 2 : 0x7ffffff0;
+            const int o0 = rg_a == rg ? afo : 0x7ffffff0, o1 = rg_b == rg ? afo + 32 * F * 2 : 0x7ffffff0;
             bf16x8 b[KBF], x[2][KBF];
 #pragma unroll
             for (int kb = 0; kb < KBF; ++kb) {
@@ -364,9 +355,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         kloop(acc, Qp);
         if (j + 1 < NT) issue_b(a.Uzf, 4 * (j + 1) + w, a.Gzrf, 4 * (j + 1) + w);
         const V8 b = bias8(a.ch + 128 * j + ec);
-        int cur = -1;                    // lanes 0..31: running sum of column 32 w + lane over the rows of node `cur`
-        float csum = 0.f;
-        float* oh = a.OH + node0 * C + 128 * j + 32 * w + lr;
+        int nd = 0, tc = t0;             // lanes 0..31: running sum of column 32 w + lane over the rows of node node0 + nd
+        float csum = 0.f;                //   (nd, tc = period of the next row: wave-uniform)
+        float* oh = a.OH + (long)node0 * C + 128 * j + 32 * w + lr;
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
@@ -374,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             const int row = 16 * rnd + er, c = 128 * j + ec;
             const V8 hv = f_widen8(*reinterpret_cast<const u32x4_t*>(Hp + plane_off(row, c)));
             const V8 Zv = f_widen8(zk[rnd]);
-            const float pt = rowtab[row].p;
+            const float pt = ptr_[rnd];
             V8 ht, bl;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -389,22 +380,25 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #pragma unroll
                 for (int r8 = 0; r8 < FT_IMG_ROWS; r8 += 8) {          // LDS reads of 8 rows first, then the serial chain on registers
                     float cv[8];
-                    int cn[8];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { cv[r] = imgw[(r8 + r) * FT_IMG_LD + lr]; cn[r] = rowtab[16 * rnd + r8 + r].node; }
+                    for (int r = 0; r < 8; ++r) cv[r] = imgw[(r8 + r) * FT_IMG_LD + lr];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        if (cn[r] != cur) {            // wave-uniform: every lane looks at the same row
-                            if (cur >= 0) atomicAdd(oh + (long)cur * C, csum);
-                            cur = cn[r];
-                            csum = 0.f;
+                        const int row = 16 * rnd + r8 + r;             // (all of this control flow is wave-uniform)
+                        if (row < nvalid) {
+                            if (tc == 0 && row > 0) {                  // the row starts a new node: hand the finished one over
+                                atomicAdd(oh + (long)nd * C, csum);
+                                ++nd;
+                                csum = 0.f;
+                            }
+                            csum += cv[r];
+                            tc = tc + 1 == a.T ? 0 : tc + 1;
                         }
-                        if (cn[r] >= 0) csum += cv[r];
                     }
                 }
             }
         }
-        if (lh == 0 && cur >= 0) atomicAdd(oh + (long)cur * C, csum);
+        if (lh == 0) atomicAdd(oh + (long)nd * C, csum);
         FT_MARK(5 + 2 * j);
     }
 #undef FT_MARK

@@ -159,6 +159,10 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ r
 // (1.6 MB at cfg-3) and stays in L2, so each X line is fetched from HBM / MALL about once.
 // Eight lanes own one (row, panel): 8 x 16 B = one 128-B line per neighbour; the 8 lanes pull 8
 // (col, val) pairs with one coalesced load and broadcast them by shuffle, four gathers in flight.
+// 256-byte panels (half the passes over the CSR, 16 lanes per row) while an XCD's slice of X (chunk x 256 B) stays NEAR its 4 MiB L2:
+// measured faster up to a 4.0 MB slice (cfg-5 shard, 15 625 nodes per XCD: 0.27 vs 0.38 ms with 128-byte panels, round 3; the
+// round-1 limit of 3.7 MB was a guess that left this case on 128-byte panels)
+constexpr long SP_WIDE_SLICE_MAX = 9L << 19;     // 4.7 MB
 template <int PL>     // lanes per row = panel width in float4: 8 = one 128-B line per neighbour, 16 = two (half the CSR re-reads)
 __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                          const float* __restrict__ val, const float* __restrict__ X,
@@ -506,7 +510,7 @@ int launch_spmm_dual_bf16(const int* rowptr, const int* col, const float* val_a,
     const long rowbytes = 2L * W;
     static int pl_env = -1;
     if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && rowbytes % 256 == 0;
+    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && rowbytes % 256 == 0;
     const int PL = wide ? 16 : 8;
     REGT_CHECK_ARG(x_rows * rowbytes < (1L << 32) - 4096, "spmm_dual (bf16 rows): X larger than 4 GB");
     if (rows_wanted() && (256 / PL) * rows_rpg(nnodes, PL, true) <= 256)
@@ -535,7 +539,7 @@ int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, co
     {
         static int pl_env0 = -1;
         if (pl_env0 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env0 = e ? atoi(e) : 0; }
-        const bool wide0 = (pl_env0 ? pl_env0 == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;
+        const bool wide0 = (pl_env0 ? pl_env0 == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;
         const int PL0 = wide0 ? 16 : 8;
         if (rows_ok(nnodes, x_rows, 4L * W, PL0))
             return launch_spmm_rows<true, false>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, 4 * W, PL0, st);
@@ -544,7 +548,7 @@ int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, co
     if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
     // two cache lines per neighbour (halves the CSR re-reads) while the XCD's slice of X (chunk x 256 B) stays
     // around the 4 MiB L2: measured 182 vs 197 us at cfg-3 (3.2 MB slice)
-    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
+    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
     const int PL = wide ? 16 : 8;
     const int npanels = W4 / PL;
     const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
@@ -594,14 +598,14 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
         if (nstack == 1) {      // one operator: the row-block kernel (CSR entries in LDS, the workgroup walks all panels)
             static int pl_env1 = -1;
             if (pl_env1 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env1 = e ? atoi(e) : 0; }
-            const bool wide1 = (pl_env1 ? pl_env1 == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;
+            const bool wide1 = (pl_env1 ? pl_env1 == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;
             if (rows_ok(nnodes, nrows_x, 4L * W, wide1 ? 16 : 8))
                 return launch_spmm_rows<false, false>(rowptr, col, val, nullptr, X, Y, nullptr, nnodes, nrows_x, 4 * W, wide1 ? 16 : 8, st);
         }
         // 256-byte panels (half the passes over the CSR) while an XCD's slice of X (chunk x 256 B) stays around its 4 MiB L2
         static int pl_env = -1;
         if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-        const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= (7L << 19)) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
+        const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
         const int PL = wide ? 16 : 8;
         const int npanels = W4 / PL;
         const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
