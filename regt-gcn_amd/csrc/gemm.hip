@@ -116,7 +116,8 @@ struct EpiBiasActF {
     struct Col { float4 b; };
     struct VAux {};
     struct Tile { __amdgpu_buffer_rsrc_t out; int v, s; };
-    __device__ __forceinline__ int variant(int) const { return e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0); }
+    // (-1 = the guarded path: the straight-line body addresses a tile with 32-bit byte offsets, 120 rows x ldo x 4 B must fit)
+    __device__ __forceinline__ int variant(int) const { return e.ldo >= (1L << 22) ? -1 : (e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0)); }
     template <int V> __device__ __forceinline__ Col vcol(int c) const { return Col{e.bias ? ld4(e.bias + c) : make_float4(0, 0, 0, 0)}; }
     template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
         return Tile{buf_srd(e.out + g.m0 * e.ldo + g.n0), (g.rr * (int)e.ldo + g.c) * 4, g.step * (int)e.ldo * 4};
@@ -359,7 +360,9 @@ struct EpiMaskAddF {
     struct Col {};
     struct VAux { float4 mk, ad; };
     struct Tile { __amdgpu_buffer_rsrc_t out, mask, add; int vo, vm, va, so, sm, sa; };
-    __device__ __forceinline__ int variant(int) const { return e.add ? 1 : 0; }
+    __device__ __forceinline__ int variant(int) const {
+        return (e.ldo >= (1L << 22) || e.ldm >= (1L << 22) || (e.add && e.ldadd >= (1L << 22))) ? -1 : (e.add ? 1 : 0);    // 32-bit tile offsets
+    }
     template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
     template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
         Tile t;
@@ -460,7 +463,7 @@ struct EpiBiasAct8F {
     typedef ColAux Col;
     struct VAux {};
     struct Tile { __amdgpu_buffer_rsrc_t out; int v, s; };
-    __device__ __forceinline__ int variant(int) const { return !e.out_bf16 ? -1 : (e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0)); }
+    __device__ __forceinline__ int variant(int) const { return (!e.out_bf16 || e.ldo >= (1L << 22)) ? -1 : (e.act == ACT_SIGMOID ? 1 : (e.act == ACT_TANH ? 2 : 0)); }
     template <int V> __device__ __forceinline__ Col vcol(int c) const { return col(c); }
     template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
         return Tile{buf_srd(reinterpret_cast<const char*>(e.out) + 2 * (g.m0 * e.ldo + g.n0)), (g.rr * (int)e.ldo + g.c) * 2, g.step * (int)e.ldo * 2};

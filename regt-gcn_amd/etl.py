@@ -36,6 +36,16 @@ REGIONS = ("IA", "KS", "KY", "OH", "WI")
 EXCLUDED_STATES = ("IL", "MI", "MN", "IN")          # load_dataset.py:342
 # columns of a node_data_*.csv row (load_dataset.py:126) that make up the 8 features, in feature order
 FEATURE_COLUMNS = (3, 4, 5, 6, 8, 9, 10, 12)        # WEEKID, DAYID, HOURID, TRAVEL_TIME, OWNER, AMENITY, CAPACITY, OCCRATE
+# the last feature (= the prediction target, load_dataset.py:453) is chosen by run.py's --tf / --train_feature
+# (load_dataset.py:417-419: ``self.train_feature.upper()``): column 11 = AVAILABLE, column 12 = OCCRATE
+TARGET_COLUMN = {"occrate": 12, "available": 11}
+
+
+def feature_columns(train_feature: str = "occrate") -> Tuple[int, ...]:
+    tf = train_feature.lower()
+    if tf not in TARGET_COLUMN:
+        raise ValueError(f"train_feature must be 'occrate' or 'available' (run.py --tf), got {train_feature!r}")
+    return FEATURE_COLUMNS[:-1] + (TARGET_COLUMN[tf],)
 
 
 @dataclass
@@ -116,8 +126,11 @@ def minmax_per_timestep(raw: np.ndarray) -> np.ndarray:
     return (raw - lo) / np.where(hi > lo, hi - lo, 1.0)
 
 
-def read_node_steps(node_dir: str, site_ids: Sequence[str], max_steps: Optional[int] = None, start: int = 0) -> torch.Tensor:
-    """All ``node_data_*.csv`` of ``node_dir`` in name (= time) order -> (N, 8, steps) float32."""
+def read_node_steps(node_dir: str, site_ids: Sequence[str], max_steps: Optional[int] = None, start: int = 0,
+                    train_feature: str = "occrate") -> torch.Tensor:
+    """All ``node_data_*.csv`` of ``node_dir`` in name (= time) order -> (N, 8, steps) float32; the eighth feature is OCCRATE or
+    AVAILABLE (``train_feature``)."""
+    FEATURE_COLUMNS = feature_columns(train_feature)
     idx = {s: i for i, s in enumerate(site_ids)}
     files = sorted(fn for fn in os.listdir(node_dir) if fn.startswith("node_data_") and fn.endswith(".csv"))
     files = files[start:None if max_steps is None else start + max_steps]
@@ -136,11 +149,11 @@ def read_node_steps(node_dir: str, site_ids: Sequence[str], max_steps: Optional[
     return torch.from_numpy(data.astype(np.float32))
 
 
-def load_tpims(root: str, max_steps: Optional[int] = None, start: int = 0) -> TpimsData:
-    """``root`` = the reference's ``dataset/`` directory."""
+def load_tpims(root: str, max_steps: Optional[int] = None, start: int = 0, train_feature: str = "occrate") -> TpimsData:
+    """``root`` = the reference's ``dataset/`` directory; ``train_feature`` = run.py's --tf (occrate / available)."""
     sites = read_sites(os.path.join(root, "data", "tpims_location.csv"))
     links = read_links(root, len(sites))
-    node_data = read_node_steps(os.path.join(root, "nodes", "0322"), sites, max_steps, start)
+    node_data = read_node_steps(os.path.join(root, "nodes", "0322"), sites, max_steps, start, train_feature)
     r_idx = [links[r][0] for r in REGIONS]
     r_att = [links[r][1] for r in REGIONS]
     if "" in links:
@@ -166,9 +179,10 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description="TPIMS dataset directory -> processed 13-tuple pickle / .npz")
     ap.add_argument("--root", required=True, help="the reference's dataset/ directory")
     ap.add_argument("--max_steps", type=int, default=None)
+    ap.add_argument("--tf", "--train_feature", default="occrate", dest="tf", choices=sorted(TARGET_COLUMN), help="target column (run.py --tf)")
     ap.add_argument("--out", required=True, help="*.pkl (reference layout) or *.npz (fixture layout)")
     a = ap.parse_args(argv)
-    d = load_tpims(a.root, a.max_steps)
+    d = load_tpims(a.root, a.max_steps, train_feature=a.tf)
     if a.out.endswith(".npz"):
         np.savez_compressed(a.out, **{k: v.numpy() for k, v in d.as_dict().items()})
     else:

@@ -504,17 +504,18 @@ class GatAggregateFunction(torch.autograd.Function):
 
 
 class ZeroGradAnchor(torch.autograd.Function):
-    """Identity on ``out`` that gives ``dead`` parameters an all-zero gradient: in the reference's GraphSAGE / GAT models the
-    reset gate is computed and multiplied by the zero hidden state, so autograd hands its parameters zeros, not None."""
+    """Identity on ``(pred, hidden)`` that gives ``dead`` parameters an all-zero gradient: in the reference's GraphSAGE / GAT models
+    the reset gate is computed and multiplied by the zero hidden state, so autograd hands its parameters zeros, not None --
+    whichever of the two outputs the loss is built from."""
 
     @staticmethod
-    def forward(ctx, out, *dead):
+    def forward(ctx, pred, hidden, *dead):
         ctx.shapes = [(d.shape, d.device) for d in dead]
-        return out.view_as(out)
+        return pred.view_as(pred), hidden.view_as(hidden)
 
     @staticmethod
-    def backward(ctx, g):
-        return (g, *[torch.zeros(s, dtype=torch.float32, device=dv) for s, dv in ctx.shapes])
+    def backward(ctx, g_pred, g_hidden):
+        return (g_pred, g_hidden, *[torch.zeros(s, dtype=torch.float32, device=dv) for s, dv in ctx.shapes])
 
 
 def regt_gcn_forward(x, graph: PreparedGraph, params: Dict[str, torch.Tensor], regional: bool = True, slope: float = 0.01):

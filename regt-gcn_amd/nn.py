@@ -401,6 +401,18 @@ class GAT(nn.Module):
         nn.init.uniform_(self._attention)
 
 
+def _pad_features(x: torch.Tensor):
+    """(N, F, T) -> the same with F rounded up to a multiple of 4 by zero feature rows, and the number of rows added.  Any node
+    feature width is accepted, as in the reference; zero features under zero weight columns change nothing, and autograd slices
+    the gradients of the padded weights back."""
+    fpad = (-x.shape[1]) % 4
+    return (torch.nn.functional.pad(x, (0, 0, 0, fpad)).contiguous() if fpad else x), fpad
+
+
+def _pad_cols(w: torch.Tensor, fpad: int) -> torch.Tensor:
+    return torch.nn.functional.pad(w, (0, fpad)) if fpad else w
+
+
 class _ZeroHiddenModel(nn.Module):
     cell_attr: str
 
@@ -413,7 +425,7 @@ class _ZeroHiddenModel(nn.Module):
                                            self.linear2.weight, self.linear2.bias, num_nodes)
         cell = self._cell()
         dead = list(cell.conv_r.parameters()) + list(cell.linear_r.parameters())     # reset gate: multiplied by H = 0
-        return ZeroGradAnchor.apply(pred, *dead), hidden
+        return ZeroGradAnchor.apply(pred, hidden, *dead)
 
 
 class GraphSAGETemporalGCN(_ZeroHiddenModel):
@@ -436,6 +448,7 @@ class GraphSAGETemporalGCN(_ZeroHiddenModel):
 
     def forward_prepared(self, x: torch.Tensor, op: MeanOperator):
         _need_cuda(x)
+        x, fpad = _pad_features(x)            # the kernels read 16-byte feature rows: zero columns for x and for the weights
         n, f, t = x.shape
         c = self.tgnn.out_channels
         cell = self.tgnn._base_tgcn
@@ -445,7 +458,7 @@ class GraphSAGETemporalGCN(_ZeroHiddenModel):
         gs, cs = [], []
         for conv, lin in ((cell.conv_z, cell.linear_z), (cell.conv_h, cell.linear_h)):
             u1 = lin.weight[:, :c].contiguous()
-            gs.append(torch.cat([_compose(u1, conv.lin_l.weight), _compose(u1, conv.lin_r.weight)], dim=1))
+            gs.append(torch.cat([_compose(u1, _pad_cols(conv.lin_l.weight, fpad)), _compose(u1, _pad_cols(conv.lin_r.weight, fpad))], dim=1))
             cs.append(_compose_bias(u1, conv.lin_l.bias, lin.bias))
         return self._run_cell0(a, a, gs[0], gs[1], cs[0], cs[1], n)
 
@@ -477,13 +490,14 @@ class GATTemporal(_ZeroHiddenModel):
 
     def forward_prepared(self, x: torch.Tensor, pat: AttentionPattern):
         _need_cuda(x)
+        x, fpad = _pad_features(x)
         n, f, t = x.shape
         c = self.gat.out_channels
         cell = self.gat._base_tgcn
         xp = ops.pack_x(x)
         ins, gs, cs = [], [], []
         for conv, lin in ((cell.conv_z, cell.linear_z), (cell.conv_h, cell.linear_h)):
-            w = conv.lin.weight                                                    # (C, F)
+            w = _pad_cols(conv.lin.weight, fpad)                                   # (C, F)
             u_src = LinearFunction.apply(conv.att_src.view(1, c), w.t().contiguous(), None).view(f)      # W^T att_src
             u_dst = LinearFunction.apply(conv.att_dst.view(1, c), w.t().contiguous(), None).view(f)
             ins.append(GatAggregateFunction.apply(xp, u_src, u_dst, pat, self.NEGATIVE_SLOPE).view(n * t, f))

@@ -109,65 +109,129 @@ def split(xs, ys, ratio: float):
     return (xs[:k], ys[:k]), (xs[k:], ys[k:])
 
 
-def main(argv=None):
+# models of run.py:115-136 that are built on the TGCN cell (the hot path and the SURVEY 8(f) baselines); the others
+# (SpatialGCN, TemporalGConvLSTM, StackedGRU, STAEformer, STID, STNorm) are out of scope
+MODELS = ("RegionalTemporalGCN", "RandomTemporalGCN", "TemporalGCN", "ConvStackedTemporalGCN", "GraphSAGETemporalGCN", "GAT", "GATTemporal")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    """run.py's flag set (run.py:22-45) -- the reference's own launch lines parse unchanged, e.g. scripts/RegionalTemporalGCN.sh:1 --
+    plus this package's data-source flags.  Flags run.py parses and never reads (--momentum, --bs, --checkpoint_path: RMSprop is
+    built from lr / decay only, run.py:145; snapshots are not batched, run.py:170) are accepted and ignored here too."""
     ap = argparse.ArgumentParser(description="RegT-GCN training loop (reference run.py flags)")
     ap.add_argument("--seed", default=42, type=int)
     ap.add_argument("--epochs", default=30, type=int)
     ap.add_argument("--lr", default=1e-3, type=float)
     ap.add_argument("--decay", default=1e-4, type=float)
+    ap.add_argument("--momentum", default=0.9, type=float, help="accepted, unused (as in run.py)")
+    ap.add_argument("--bs", "--batch_size", default=32, type=int, dest="bs", help="accepted, unused (as in run.py)")
     ap.add_argument("--tr", "--train_ratio", default=0.8, type=float, dest="tr")
+    ap.add_argument("--tf", "--train_feature", default="available", type=str, dest="tf", help="occrate / available: the target column (run.py:31)")
+    ap.add_argument("--edge_cut", default=None, type=str, help="dataloading_type 1 only in run.py; accepted, unused")
+    ap.add_argument("--dataset_path", default=None, type=str, help="the reference's dataset/ directory (= --dataset_root)")
+    ap.add_argument("--checkpoint_path", default="../checkpoints/", type=str, help="accepted, unused (as in run.py)")
+    ap.add_argument("--dataloading_type", default=2, type=int, help="2 (TruckParkingDataset2 semantics) is what this loader implements")
+    ap.add_argument("--decomp_type", default=None, type=str, help="regional: the five state link files; random: run.py's random decomposition "
+                                                                  "(load_dataset.py:324-329) of the full graph into five overlapping parts")
     ap.add_argument("--num_timesteps_in", default=8, type=int)
     ap.add_argument("--num_timesteps_out", default=4, type=int)
-    ap.add_argument("--model", default="RegionalTemporalGCN", choices=["RegionalTemporalGCN", "TemporalGCN", "ConvStackedTemporalGCN"])
+    ap.add_argument("--model", default="TemporalGCN", choices=list(MODELS))
+    ap.add_argument("--is_preprocessed", action="store_true", help="accepted: the data source decides (a .pkl / .npz is preprocessed by definition)")
+    ap.add_argument("--is_pretrained", action="store_true")
+    ap.add_argument("--pretrained_model", default="")
+    ap.add_argument("--pretrained_model_epoch", default="0")
+    ap.add_argument("--logs", action="store_true", help="also write the epoch lines to ./logs/<date>.txt (run.py:48-49)")
+    # this package's own flags
     ap.add_argument("--fixture", help=".npz with node_data (N,F,steps), edge_index, edge_attr, edge_<R>_index/attr")
     ap.add_argument("--dataset_root", help="the reference's dataset/ directory (read through regtgcn_amd.etl)")
     ap.add_argument("--max_steps", type=int, default=None, help="with --dataset_root: use the first MAX_STEPS timesteps")
     ap.add_argument("--out_dir", default="pretrained")
     ap.add_argument("--fused_step", action="store_true", help="train through functional.FusedTrainStep (no autograd; faster on small graphs)")
-    ap.add_argument("--is_pretrained", action="store_true")
-    ap.add_argument("--pretrained_model", default="")
-    ap.add_argument("--pretrained_model_epoch", default="0")
-    a = ap.parse_args(argv)
+    return ap
+
+
+def random_decomposition(edge_index: torch.Tensor, edge_attr: torch.Tensor, parts: int = 5, seed: int = 42):
+    """run.py --decomp_type random.  The reference reads five files links/0322/link{1..5}_data.csv there (load_dataset.py:324-329)
+    that its repository does not ship; what they hold is a split of the full graph's edges into five parts that ignores the
+    states.  Here the five parts are drawn (seeded) from the full edge list, so a node may receive edges in several of them --
+    the "overlapping" layout of graph.prepare_graph, the general form of the regional embedding."""
+    g = torch.Generator().manual_seed(seed)
+    e = edge_index.shape[1]
+    idx, att = [], []
+    for _ in range(parts):
+        pick = torch.randperm(e, generator=g)[: max(1, e // parts)]
+        idx.append(edge_index[:, pick].contiguous())
+        att.append(edge_attr[pick].contiguous())
+    return idx, att
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     torch.manual_seed(a.seed)
     dev = torch.device("cuda:0")
-    if a.dataset_root:
+    if a.dataloading_type != 2:
+        raise SystemExit("--dataloading_type 2 (TruckParkingDataset2: full graph + five regional graphs) is the loader this package implements")
+    root = a.dataset_root or (a.dataset_path if a.dataset_path and os.path.isdir(os.path.join(a.dataset_path, "nodes")) else None)
+    if root:
         from . import etl
-        d = {k: v.numpy() for k, v in etl.load_tpims(a.dataset_root, a.max_steps).as_dict().items()}
+        d = {k: v.numpy() for k, v in etl.load_tpims(root, a.max_steps, train_feature=a.tf).as_dict().items()}
     elif a.fixture:
         d = np.load(a.fixture)
+        if a.tf.lower() != "occrate":
+            print("note: a fixture's target column is fixed when it is built (tests/golden/tpims_fixture.npz: OCCRATE); --tf is not applied")
     else:
-        raise SystemExit("give --fixture or --dataset_root")
+        raise SystemExit("give --fixture, --dataset_root or a --dataset_path that holds the reference's dataset/ directory")
     node_data = torch.from_numpy(d["node_data"])
     n, f = node_data.shape[:2]
     xs, ys = snapshot_windows(node_data, a.num_timesteps_in, a.num_timesteps_out)
     xs, ys = [x.to(dev) for x in xs], [y.to(dev) for y in ys]
     (tx, ty), (vx, vy) = split(xs, ys, a.tr)
     ei = torch.from_numpy(d["edge_index"]).to(dev)
-    if a.model == "RegionalTemporalGCN":
+    ea = torch.from_numpy(d["edge_attr"]).to(dev)
+    if a.model in ("RegionalTemporalGCN", "RandomTemporalGCN"):             # run.py:115-116: one class for both decompositions
         model = rnn.RegionalTemporalGCN(f, n, a.num_timesteps_in, a.num_timesteps_out).to(dev)
-        graph = model.prepare_graph(ei, [torch.from_numpy(d[f"edge_{r}_index"]).to(dev) for r in REGIONS],
-                                    [torch.from_numpy(d[f"edge_{r}_attr"]).to(dev) for r in REGIONS])
+        if (a.decomp_type or "regional").lower() == "random":
+            r_idx, r_att = random_decomposition(ei, ea, len(REGIONS), a.seed)
+        else:
+            r_idx = [torch.from_numpy(d[f"edge_{r}_index"]).to(dev) for r in REGIONS]
+            r_att = [torch.from_numpy(d[f"edge_{r}_attr"]).to(dev) for r in REGIONS]
+        graph = model.prepare_graph(ei, r_idx, r_att)
     elif a.model == "TemporalGCN":
         model = rnn.TemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
-        graph = model.prepare_graph(ei, torch.from_numpy(d["edge_attr"]).to(dev), n)
-    else:                                                                   # run.py:125-126
+        graph = model.prepare_graph(ei, ea, n)
+    elif a.model == "ConvStackedTemporalGCN":                               # run.py:125-126
         model = rnn.ConvStackedTemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
-        graph = model.prepare_graph(ei, torch.from_numpy(d["edge_attr"]).to(dev), n)
+        graph = model.prepare_graph(ei, ea, n)
+    elif a.model == "GraphSAGETemporalGCN":                                 # run.py:127-128
+        model = rnn.GraphSAGETemporalGCN(f, n, a.num_timesteps_in, a.num_timesteps_out).to(dev)
+        graph = model.prepare_graph(ei, n)
+    else:                                                                   # 'GAT' in run.py:129-130 (class GATTemporal)
+        model = rnn.GATTemporal(f, n, a.num_timesteps_in, a.num_timesteps_out).to(dev)
+        graph = model.prepare_graph(ei, n)
     if a.is_pretrained:
         model.load_state_dict(torch.load(a.pretrained_model, map_location=dev, weights_only=True))
     opt = torch.optim.RMSprop(model.parameters(), lr=a.lr, weight_decay=a.decay)
-    out_dir = os.path.join(a.out_dir, a.model)
+    out_dir = os.path.join(a.out_dir, a.tf, a.model)                         # run.py:138, 243: pretrained/<tf>/<model>/
     os.makedirs(out_dir, exist_ok=True)
+    log = None
+    if a.logs:
+        import datetime
+        os.makedirs("logs", exist_ok=True)
+        log = open(os.path.join("logs", datetime.datetime.now().strftime("%y-%m-%d_%H-%M") + ".txt"), "a")
     stepper = None
     if a.fused_step:
-        if a.model == "ConvStackedTemporalGCN":
-            raise SystemExit("--fused_step covers RegionalTemporalGCN / TemporalGCN")
+        if a.model not in ("RegionalTemporalGCN", "RandomTemporalGCN", "TemporalGCN") or getattr(graph, "overlap", False):
+            raise SystemExit("--fused_step covers RegionalTemporalGCN (regional decomposition) / TemporalGCN")
         from .functional import FusedTrainStep
         stepper = FusedTrainStep(model, graph, f, a.num_timesteps_in)
     for epoch in range(a.epochs + 1):
         last, _ = train_epoch(model, tx, ty, graph, opt, stepper)
         rmse, mse = evaluate(model, vx, vy, graph)
-        print("Train Loss: {:.4f}, Test RMSE: {:.4f}, MAE: {:.4f}".format(float(last), rmse, mse))   # run.py:236 format
+        line = "Train Loss: {:.4f}, Test RMSE: {:.4f}, MAE: {:.4f}".format(float(last), rmse, mse)   # run.py:236 format
+        print(line)
+        if log:
+            log.write(line + "\n")
+            log.flush()
         if epoch % 10 == 0:
             torch.save(model.state_dict(), os.path.join(out_dir, "model_in{}_out{}_epoch{}.pt".format(
                 a.num_timesteps_in, a.num_timesteps_out, int(a.pretrained_model_epoch) + epoch)))

@@ -109,3 +109,28 @@ def test_zero_hidden_models_keep_reference_layout():
             m(torch.zeros(104, 8, 6), torch.zeros(2, 0, dtype=torch.long), None)
     with pytest.raises(NotImplementedError):
         R.TGCN(8, 16, baseblock="transformer")
+
+
+def test_reference_launch_line_parses():
+    """The argument string of the reference's own launch script (scripts/RegionalTemporalGCN.sh:1, copied here as a string) is
+    accepted by the run.py counterpart, with run.py's defaults for everything it leaves out (run.py:22-45)."""
+    from regtgcn_amd import train
+    line = "--num_timesteps_in 6 --num_timesteps_out 1 --tr 0.2 --model RegionalTemporalGCN --tf occrate --dataloading_type 2 --epochs 50 --decomp_type regional"
+    a = train.build_parser().parse_args(line.split())
+    assert (a.num_timesteps_in, a.num_timesteps_out, a.tr, a.model, a.tf, a.dataloading_type, a.epochs, a.decomp_type) == \
+        (6, 1, 0.2, "RegionalTemporalGCN", "occrate", 2, 50, "regional")
+    d = train.build_parser().parse_args([])
+    assert (d.seed, d.lr, d.decay, d.momentum, d.bs, d.tf, d.model, d.num_timesteps_in, d.num_timesteps_out, d.checkpoint_path) == \
+        (42, 1e-3, 1e-4, 0.9, 32, "available", "TemporalGCN", 8, 4, "../checkpoints/")
+    for flags in ("--train_ratio 0.5 --batch_size 8 --train_feature available --edge_cut random --dataset_path ./dataset --is_preprocessed --logs",
+                  "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random",
+                  "--is_pretrained --pretrained_model m.pt --pretrained_model_epoch 10"):
+        train.build_parser().parse_args(flags.split())
+
+
+def test_etl_target_column_follows_train_feature():
+    from regtgcn_amd import etl
+    assert etl.feature_columns("occrate")[-1] == 12 and etl.feature_columns("AVAILABLE")[-1] == 11
+    assert etl.feature_columns("occrate")[:-1] == etl.feature_columns("available")[:-1]
+    with pytest.raises(ValueError):
+        etl.feature_columns("speed")

@@ -62,6 +62,19 @@ def test_etl_reads_reference_layout(tmp_path):
         R.etl._parse_links([["0", "a", "77", "b", "1.0"]], 6)
 
 
+def test_etl_available_target_column(tmp_path):
+    """run.py --tf available (load_dataset.py:417-419): the eighth feature -- the prediction target -- is the AVAILABLE column."""
+    kept, pairs, raws = _write_dataset(tmp_path)
+    occ = R.etl.load_tpims(str(tmp_path), train_feature="occrate")
+    av = R.etl.load_tpims(str(tmp_path), train_feature="available")
+    assert torch.equal(occ.node_data[:, :7], av.node_data[:, :7])
+    for t, raw in enumerate(raws):
+        col = raw[:, 11]
+        want = (col - col.min()) / (col.max() - col.min())
+        np.testing.assert_allclose(av.node_data[:, 7, t].numpy(), want, atol=1e-6)
+    assert not torch.equal(occ.node_data[:, 7], av.node_data[:, 7])
+
+
 def test_processed_tuple_round_trip(tmp_path):
     _write_dataset(tmp_path)
     d = R.etl.load_tpims(str(tmp_path), max_steps=3)

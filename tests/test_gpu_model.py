@@ -443,3 +443,26 @@ print("OK", list(st))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = subprocess.run([sys.executable, "-c", script], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("extra", ["", "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random"],
+                         ids=["reference_line", "graphsage", "gat", "random_decomposition"])
+def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra):
+    """scripts/RegionalTemporalGCN.sh:1's argument string (copied as a string; --epochs cut to 1) drives the run.py counterpart on
+    the TPIMS fixture: epochs + 1 iterations (run.py:230), the run.py:236 line per epoch, a checkpoint with the reference's file
+    name under pretrained/<tf>/<model>/ (run.py:138, 243) that strict-loads into a fresh module."""
+    from regtgcn_amd import train
+    line = "--num_timesteps_in 6 --num_timesteps_out 1 --tr 0.2 --model RegionalTemporalGCN --tf occrate --dataloading_type 2 --epochs 1 --decomp_type regional"
+    argv = line.split() + extra.split() + ["--fixture", os.path.join(GOLDEN, "tpims_fixture.npz"), "--out_dir", str(tmp_path)]
+    train.main(argv)
+    a = train.build_parser().parse_args(argv)
+    lines = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("Train Loss:")]
+    assert len(lines) == 2 and all("Test RMSE:" in ln and "MAE:" in ln for ln in lines)
+    ck = tmp_path / "occrate" / a.model / "model_in6_out1_epoch0.pt"
+    assert ck.exists()
+    sd = torch.load(str(ck), map_location="cpu", weights_only=True)
+    n = np.load(os.path.join(GOLDEN, "tpims_fixture.npz"))["node_data"].shape[0]
+    cls = {"RegionalTemporalGCN": R.RegionalTemporalGCN, "RandomTemporalGCN": R.RegionalTemporalGCN, "GraphSAGETemporalGCN": R.GraphSAGETemporalGCN,
+           "GAT": R.GATTemporal}[a.model]
+    cls(8, n, 6, 1).load_state_dict(sd, strict=True)
+    assert all(bool(torch.isfinite(v).all()) for v in sd.values())

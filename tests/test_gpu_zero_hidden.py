@@ -111,7 +111,8 @@ def test_zero_hidden_models_match_reference_goldens(R, tpims, name, short, tag):
 
 
 @pytest.mark.parametrize("name", ["GraphSAGETemporalGCN", "GATTemporal"])
-@pytest.mark.parametrize("n,e,f,t,o,hidden", [(1500, 15000, 32, 12, 1, 256), (400, 3000, 8, 6, 3, 256), (700, 5000, 12, 5, 2, 132)])
+@pytest.mark.parametrize("n,e,f,t,o,hidden", [(1500, 15000, 32, 12, 1, 256), (400, 3000, 8, 6, 3, 256), (700, 5000, 12, 5, 2, 132),
+                                              (300, 2000, 7, 4, 1, 256), (250, 1500, 6, 3, 2, 256)])     # F = 7, 6: padded feature rows
 def test_zero_hidden_models_match_oracle_on_synthetic_graphs(R, name, n, e, f, t, o, hidden):
     ei = _graph(n, e, n + f)
     gen = torch.Generator().manual_seed(n)
@@ -133,3 +134,20 @@ def test_zero_hidden_models_match_oracle_on_synthetic_graphs(R, name, n, e, f, t
             assert q.grad is None, k
             continue
         np.testing.assert_allclose(q.grad.cpu().numpy(), po[k].grad.numpy(), atol=TOL, rtol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["GraphSAGETemporalGCN", "GATTemporal"])
+def test_dead_reset_gate_gets_zero_gradients_from_either_output(R, name):
+    """A loss built from ``hidden`` alone still hands the reset gate's parameters zeros (not None), as the reference's autograd does."""
+    n, e, f, t, o = 200, 1500, 8, 4, 1
+    ei = _graph(n, e, 3)
+    p = M.init_params(name, f, t, o, num_nodes=n, seed=5)
+    mod = getattr(R, name)(node_features=f, num_nodes=n, periods=t, output_dim=o)
+    mod.load_state_dict(p, strict=True)
+    mod = mod.cuda()
+    _, hid = mod(torch.rand(n, f, t).cuda(), ei.cuda(), None)
+    hid.sum().backward()
+    pre = "tgnn." if name == "GraphSAGETemporalGCN" else "gat."
+    g = dict(mod.named_parameters())[f"{pre}_base_tgcn.linear_r.weight"].grad
+    assert g is not None and float(g.abs().max()) == 0.0
+    assert dict(mod.named_parameters())["linear1.weight"].grad is None          # the head is not on hidden's path
