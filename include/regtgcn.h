@@ -49,6 +49,13 @@ int32_t regt_gcn_csr(const int64_t* edge_index, const float* edge_weight, int64_
                      int32_t* rowptr, int32_t* col, float* val, int32_t* flags_dev,
                      void* workspace, size_t workspace_bytes, regt_stream_t stream);
 
+/* D^-1/2 of that normalisation alone: dis_out (N) = (in-degree sum in edge order + self loop)^-1/2, 0 where the degree is 0 --
+ * the value regt_gcn_csr multiplies into every entry.  A region shard computes it for its own nodes and publishes it (one
+ * all-reduce at graph preparation) so that the ranks that read those nodes as halo sources can finish their rows of A_hat
+ * without normalising the global graph. */
+int32_t regt_gcn_dis(const int64_t* edge_index, const float* edge_weight, int64_t num_edges, int32_t num_nodes, float* dis_out,
+                     int32_t* flags_dev, void* workspace, size_t workspace_bytes, regt_stream_t stream);
+
 /* Per-edge scaled-Laplacian weights of ChebConv(K=2, 'sym', lambda_max=None): out_weight (E). */
 int32_t regt_cheb_edge_weights(const int64_t* edge_index, const float* edge_weight, int64_t num_edges,
                                int32_t num_nodes, float* out_weight, int32_t* flags_dev,

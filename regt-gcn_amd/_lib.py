@@ -69,6 +69,7 @@ SIGNATURES = {
     "regt_last_error": (C.c_char_p, []),
     "regt_graph_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "regt_gcn_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "regt_gcn_dis": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "regt_cheb_edge_weights": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "regt_raw_csr": (C.c_int32, [vp, vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_size_t, vp]),
     "regt_graph_fingerprint": (C.c_int32, [vp, vp, C.c_int64, vp, vp]),

@@ -927,6 +927,12 @@ int32_t regt_gcn_csr(const int64_t* ei, const float* w, int64_t E, int32_t N, in
     return graph_gcn_csr(ei, w, (long)E, N, rowptr, col, val, flags_dev, ws, ws_bytes, (hipStream_t)st);
 }
 
+int32_t regt_gcn_dis(const int64_t* ei, const float* w, int64_t E, int32_t N, float* dis_out, int32_t* flags_dev, void* ws, size_t ws_bytes,
+                     regt_stream_t st) {
+    REGT_CHECK_ARG((ei || E == 0) && dis_out && flags_dev && ws, "regt_gcn_dis: NULL pointer");
+    return graph_gcn_dis(ei, w, (long)E, N, dis_out, flags_dev, ws, ws_bytes, (hipStream_t)st);
+}
+
 int32_t regt_cheb_edge_weights(const int64_t* ei, const float* w, int64_t E, int32_t N, float* out, int32_t* flags_dev,
                                void* ws, size_t ws_bytes, regt_stream_t st) {
     REGT_CHECK_ARG((ei || E == 0) && (out || E == 0) && flags_dev && ws, "regt_cheb_edge_weights: NULL pointer");

@@ -248,6 +248,23 @@ int graph_gcn_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr,
     return REGT_OK;
 }
 
+// D^-1/2 of GCNConv's normalisation (in-degree sums in edge order + the self loop, exactly as graph_gcn_csr forms them): what a
+// region shard publishes for its own nodes so that the ranks that read them as halo sources can finish their A_hat rows.
+int graph_gcn_dis(const int64_t* ei, const float* w, long E, int N, float* dis_out, int* flags_out_dev, void* ws, size_t ws_bytes,
+                  hipStream_t st) {
+    REGT_CHECK_ARG(N > 0 && E >= 0, "graph: N=%d E=%ld", N, E);
+    REGT_CHECK_ARG(ws_bytes >= graph_workspace_bytes(E, N), "graph: workspace too small");
+    Ws W;
+    ws_layout(E, N, (char*)ws, &W);
+    REGT_CHECK_HIP(hipMemsetAsync(W.flags, 0, 256, st));
+    int rc = bucket(ei, E, N, /*key=dst*/ 1, /*extra*/ 1, W, W.ptr, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_degree, dim3(nblk(N)), dim3(TPB), 0, st, W.ptr, W.cnt, W.eid, w, W.loop_eid, 1, N, dis_out, W.loopw, W.flags);
+    REGT_CHECK_LAUNCH();
+    REGT_CHECK_HIP(hipMemcpyAsync(flags_out_dev, W.flags, 4, hipMemcpyDeviceToDevice, st));
+    return REGT_OK;
+}
+
 int graph_cheb_edge_weights(const int64_t* ei, const float* w, long E, int N, float* out_w, int* flags_out_dev,
                             void* ws, size_t ws_bytes, hipStream_t st) {
     REGT_CHECK_ARG(N > 0 && E >= 0, "graph: N=%d E=%ld", N, E);

@@ -192,6 +192,8 @@ int launch_small_gemm_multi(SgBatch& b, hipStream_t st);
 size_t graph_workspace_bytes(long E, int N);
 int graph_gcn_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,
                   int* flags_out_dev, void* ws, size_t ws_bytes, hipStream_t st);
+int graph_gcn_dis(const int64_t* ei, const float* w, long E, int N, float* dis_out, int* flags_out_dev, void* ws, size_t ws_bytes,
+                  hipStream_t st);
 int graph_cheb_edge_weights(const int64_t* ei, const float* w, long E, int N, float* out_w, int* flags_out_dev,
                             void* ws, size_t ws_bytes, hipStream_t st);
 int graph_raw_csr(const int64_t* ei, const float* w, long E, int N, int* rowptr, int* col, float* val,

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .graph import PreparedGraph, cheb_edge_weights, gcn_csr, merge_operators, node_regions, raw_csr
+from .graph import PreparedGraph, cheb_edge_weights, gcn_csr, gcn_dis, merge_operators, node_regions, raw_csr
 
 
 @dataclass
@@ -94,6 +94,35 @@ def shard_topology(edge_index: np.ndarray, owner_bounds: np.ndarray, rank: int, 
     need = [np.unique(src[(do == rank) & (so == s)]) if s != rank else empty for s in range(world)]
     send = [np.unique(src[(so == rank) & (do == r)]) if r != rank else empty for r in range(world)]
     return ShardTopology(rank, world, int(owner_bounds[rank]), int(owner_bounds[rank + 1]), need, send)
+
+
+def topology_from_sources(sources: np.ndarray, owner_bounds: np.ndarray, rank: int, world: int, group=None) -> ShardTopology:
+    """The same topology from THIS rank's in-edges alone.  ``sources``: global ids of the sources of the edges whose target the
+    rank owns (any order, duplicates allowed).  ``need`` follows locally; ``send`` is what the other ranks need from this one:
+    one all-gather of the list lengths and one all-to-all of the id lists at graph preparation (a rank never walks the global
+    edge list).  Works with 'gloo' on CPU tensors and with 'nccl' (RCCL) on the current GPU."""
+    lo, hi = int(owner_bounds[rank]), int(owner_bounds[rank + 1])
+    src = np.unique(np.asarray(sources, dtype=np.int64))
+    src = src[(src < lo) | (src >= hi)]
+    owner = np.searchsorted(owner_bounds, src, side="right") - 1
+    empty = np.zeros(0, dtype=np.int64)
+    need = [src[owner == s] if s != rank else empty for s in range(world)]
+    if world == 1:
+        return ShardTopology(rank, world, lo, hi, need, [empty])
+    if not dist.is_initialized() or dist.get_world_size(group) != world:
+        raise RuntimeError("topology_from_sources needs a process group of `world` ranks (the send lists come from the peers)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    counts = torch.tensor([a.size for a in need], dtype=torch.int64, device=dev)
+    table = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(table, counts, group=group)                        # table[r][s] = how many ids rank r needs from rank s
+    send_counts = [int(table[r][rank]) for r in range(world)]
+    out = torch.empty(sum(send_counts), dtype=torch.int64, device=dev)
+    inp = torch.from_numpy(np.concatenate(need) if sum(a.size for a in need) else empty).to(dev)
+    dist.all_to_all_single(out, inp, send_counts, [a.size for a in need], group=group)
+    out = out.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(send_counts)])
+    send = [out[offs[r]:offs[r + 1]].copy() if r != rank else empty for r in range(world)]
+    return ShardTopology(rank, world, lo, hi, need, send)
 
 
 # Rehearsal aid (bench.py --force-shard-path): issue the collectives even in a 1-rank group, so that the exact RCCL calls
@@ -201,32 +230,74 @@ class Shard:
     send_idx: torch.Tensor         # (sum send_splits,) int64 on the device
 
 
+def _own_rows_operator(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], num_nodes: int, owner_bounds: np.ndarray,
+                       rank: int, world: int, device, group=None):
+    """A_hat rows of the owned nodes without normalising the global graph: the rank keeps the edges whose
+    TARGET it owns (one vectorised filter on the device), normalises that reduced graph -- owned nodes see all of their
+    in-edges there, so their degrees and rows come out right, halo sources get degree 1 -- and multiplies the entries of halo
+    columns by the sources' true D^-1/2, which every rank publishes for its own nodes with one all-reduce of a length-N
+    vector (each rank fills its slice; 4 MB at 1M nodes).  With unit edge weights (RegT-GCN: edge_weight=None) the result is
+    bit-identical to slicing the globally normalised operator: (d_j * 1) * d_i and (1 * 1) * d_i * d_j round the same."""
+    lo, hi = int(owner_bounds[rank]), int(owner_bounds[rank + 1])
+    n_local = hi - lo
+    ei = edge_index.to(device)
+    mine = (ei[1] >= lo) & (ei[1] < hi)
+    src, dst = ei[0][mine], ei[1][mine] - lo
+    w = None if gcn_weight is None else gcn_weight.to(device)[mine].contiguous()
+    local = (src >= lo) & (src < hi)
+    topo = topology_from_sources(src[~local].cpu().numpy(), owner_bounds, rank, world, group)
+    halo = torch.from_numpy(topo.halo_ids()).to(device)
+    pos = torch.searchsorted(halo, src) if halo.numel() else torch.zeros_like(src)
+    red = torch.stack([torch.where(local, src - lo, n_local + pos), dst]).contiguous()
+    rp, col, val = gcn_csr(red, w, topo.x_rows)
+    e = int(rp[n_local].item())
+    rp_a, col_a, val_a = rp[:n_local + 1].contiguous(), col[:e].contiguous(), val[:e].clone()
+    if world > 1:
+        dis = torch.zeros(num_nodes, dtype=torch.float32, device=device)
+        dis[lo:hi] = gcn_dis(red, w, topo.x_rows)[:n_local]
+        allreduce_sum(dis, group)
+        is_halo = col_a >= n_local
+        val_a[is_halo] = val_a[is_halo] * dis[halo[(col_a[is_halo] - n_local).long()]]
+    return topo, rp_a, col_a, val_a
+
+
 def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], region_attr: Sequence[torch.Tensor],
                 num_nodes: int, owner_bounds: np.ndarray, region_owner: Sequence[int], rank: int, world: int,
-                device, gcn_weight: Optional[torch.Tensor] = None) -> Shard:
+                device, gcn_weight: Optional[torch.Tensor] = None, group=None, method: Optional[str] = None) -> Shard:
     """GPU graph preparation for one rank.  ``edge_index`` etc. are the GLOBAL graph (host tensors);
-    ``region_owner[r]`` is the rank that owns region r (its nodes lie inside that rank's range)."""
-    topo = shard_topology(edge_index.cpu().numpy(), owner_bounds, rank, world)
-    lo, hi = topo.node_lo, topo.node_hi
-    # A_hat needs GLOBAL degrees (the deterministic, edge-ordered sums of graph.hip): normalise the global edge list on this
-    # rank's GPU, then keep the rows of the owned nodes and remap their columns to the extended input -- all on the device
-    # (the slice bounds are the only values read back).  One-time work per static graph; the replacement that avoids
-    # touching foreign rows at all is own rows + an all-gather of the degree vector (DESIGN.md section 7).
-    rp, col, val = gcn_csr(edge_index.to(device), None if gcn_weight is None else gcn_weight.to(device), num_nodes)
-    b, e = (int(v) for v in rp[[lo, hi]].tolist())
-    rp_a = (rp[lo:hi + 1] - b).to(torch.int32).contiguous()
-    cols = col[b:e].long()
-    local = (cols >= lo) & (cols < hi)
-    halo = torch.from_numpy(topo.halo_ids()).to(device)               # ascending global ids of the halo rows
-    pos = torch.searchsorted(halo, cols.clamp(min=0)) if halo.numel() else torch.zeros_like(cols)
-    if halo.numel():
-        hit = halo[pos.clamp(max=halo.numel() - 1)] == cols
+    ``region_owner[r]`` is the rank that owns region r (its nodes lie inside that rank's range).
+
+    ``method`` "own_rows" (default whenever the process group has ``world`` ranks): every rank normalises only the edges into
+    its own nodes and the ranks exchange degrees and need lists (:func:`_own_rows_operator`).  "global": the rank walks and
+    normalises the whole edge list by itself -- the form a single process needs when it plays one rank of a larger job
+    (``bench.py --workload cfg5shard``, tests), and the reference the own-rows form is compared with bit for bit."""
+    if method is None:
+        method = os.environ.get("REGT_SHARD_BUILD") or ("own_rows" if world == 1 or (dist.is_initialized() and dist.get_world_size(group) == world) else "global")
+    if method not in ("own_rows", "global"):
+        raise ValueError("build_shard: method must be 'own_rows' or 'global'")
+    if method == "own_rows":
+        topo, rp_a, col_a, val_a = _own_rows_operator(edge_index, gcn_weight, num_nodes, owner_bounds, rank, world, device, group)
+        lo, hi = topo.node_lo, topo.node_hi
     else:
-        hit = torch.zeros_like(local)
-    if not bool((local | hit).all()):
-        raise RuntimeError("halo source is not in this rank's need list")
-    col_a = torch.where(local, cols - lo, topo.n_local + pos).to(torch.int32).contiguous()
-    val_a = val[b:e].contiguous()
+        topo = shard_topology(edge_index.cpu().numpy(), owner_bounds, rank, world)
+        lo, hi = topo.node_lo, topo.node_hi
+        # normalise the global edge list on this rank's GPU, then keep the rows of the owned nodes and remap their columns to the
+        # extended input -- all on the device (the slice bounds are the only values read back)
+        rp, col, val = gcn_csr(edge_index.to(device), None if gcn_weight is None else gcn_weight.to(device), num_nodes)
+        b, e = (int(v) for v in rp[[lo, hi]].tolist())
+        rp_a = (rp[lo:hi + 1] - b).to(torch.int32).contiguous()
+        cols = col[b:e].long()
+        local = (cols >= lo) & (cols < hi)
+        halo = torch.from_numpy(topo.halo_ids()).to(device)               # ascending global ids of the halo rows
+        pos = torch.searchsorted(halo, cols.clamp(min=0)) if halo.numel() else torch.zeros_like(cols)
+        if halo.numel():
+            hit = halo[pos.clamp(max=halo.numel() - 1)] == cols
+        else:
+            hit = torch.zeros_like(local)
+        if not bool((local | hit).all()):
+            raise RuntimeError("halo source is not in this rank's need list")
+        col_a = torch.where(local, cols - lo, topo.n_local + pos).to(torch.int32).contiguous()
+        val_a = val[b:e].contiguous()
     # regional Laplacians of the owned regions, in local ids
     mine = [r for r in range(len(region_index)) if region_owner[r] == rank]
     if not mine:

@@ -116,6 +116,24 @@ def gcn_csr(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_n
     return rowptr, col[:nnz], val[:nnz]
 
 
+def gcn_dis(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> torch.Tensor:
+    """D^-1/2 of gcn_norm (in-degree + self loop) per node, in the arithmetic of :func:`gcn_csr`."""
+    lib = _lib.load()
+    _check_edges(edge_index, edge_weight, "gcn_dis")
+    dev = edge_index.device
+    ei = edge_index.contiguous()
+    ew = None if edge_weight is None else edge_weight.contiguous()
+    e = ei.shape[1]
+    dis = torch.empty(num_nodes, dtype=torch.float32, device=dev)
+    flags = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = lib.regt_graph_workspace_bytes(e, num_nodes)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    _lib.check(lib.regt_gcn_dis(_lib.ptr(ei), _lib.ptr(ew), e, num_nodes, _lib.ptr(dis), _lib.ptr(flags), _lib.ptr(ws), wsb, _stream()),
+               "regt_gcn_dis")
+    _raise_flags(flags, "gcn_dis")
+    return dis
+
+
 def cheb_edge_weights(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> torch.Tensor:
     """Per-edge scaled-Laplacian weights (ChebConv.__norm__ with lambda_max=None), computed once."""
     lib = _lib.load()

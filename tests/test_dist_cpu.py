@@ -29,6 +29,14 @@ def _worker(rank, world, port, n_per, e_per, regions_per, width, q):
         g = R.data.synthetic_regional_graph(n, e_per * world, regions_per * world, seed=7, p_intra=0.8)
         bounds = np.arange(world + 1, dtype=np.int64) * n_per
         topo = R.dist.shard_topology(g.edge_index.numpy(), bounds, rank, world)
+        # the same lists from this rank's in-edges alone (need: local; send: one all-gather + one all-to-all between the ranks) --
+        # what build_shard uses so that no rank walks the global edge list -- bit for bit
+        ei_np = g.edge_index.numpy()
+        mine_np = (ei_np[1] >= bounds[rank]) & (ei_np[1] < bounds[rank + 1])
+        t2 = R.dist.topology_from_sources(ei_np[0][mine_np], bounds, rank, world)
+        assert (t2.node_lo, t2.node_hi) == (topo.node_lo, topo.node_hi)
+        assert all(np.array_equal(a, b) for a, b in zip(t2.need, topo.need)), "need lists differ"
+        assert all(np.array_equal(a, b) for a, b in zip(t2.send, topo.send)), "send lists differ"
         gen = torch.Generator().manual_seed(3)
         x_glob = torch.randn(n, width, generator=gen)                 # "packed" rows of the global graph
         lo, hi = topo.node_lo, topo.node_hi

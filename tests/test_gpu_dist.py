@@ -50,7 +50,13 @@ def _worker(rank, port, q):
         model = model.cuda()
         bounds = np.arange(WORLD + 1, dtype=np.int64) * N_PER
         owner = [r // REG_PER for r in range(REG_PER * WORLD)]
-        sh = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, n, bounds, owner, rank, WORLD, "cuda")
+        sh = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, n, bounds, owner, rank, WORLD, "cuda")      # own rows only
+        # ... which is, bit for bit, the slice of the globally normalised operator (the form every rank used to build by itself)
+        ref = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, n, bounds, owner, rank, WORLD, "cuda", method="global")
+        for name in ("rowptr", "col", "val", "m_rowptr", "m_col", "m_val_a", "m_val_l", "node_region"):
+            assert torch.equal(getattr(sh.graph, name), getattr(ref.graph, name)), f"own-rows shard differs from the global build in {name}"
+        assert torch.equal(sh.send_idx, ref.send_idx) and np.array_equal(sh.topo.halo_ids(), ref.topo.halo_ids())
+        assert sh.topo.send_splits == ref.topo.send_splits and sh.topo.recv_splits == ref.topo.recv_splits
         pipe = R.dist.HaloPipeline(sh, T, F, torch.device("cuda", 0))
         lo, hi = sh.topo.node_lo, sh.topo.node_hi
         xs = [x[lo:hi].contiguous().cuda() for x, _ in snaps]
