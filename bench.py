@@ -114,8 +114,6 @@ def cpu_baseline(nodes, edges, regions, F, T, O, seed=42, model_regions=None, sc
     import regtgcn_amd as R
     from oracle import model as M
     info = host_info()
-    cores = min(info["affinity_cpus"], 16)      # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe)
-    torch.set_num_threads(cores)
     g = R.data.synthetic_regional_graph(nodes, edges, regions, seed=seed)
     (x, y), = R.data.synthetic_snapshots(nodes, F, 1, O, 1, seed=seed)
     mr = model_regions or regions
@@ -123,22 +121,40 @@ def cpu_baseline(nodes, edges, regions, F, T, O, seed=42, model_regions=None, sc
     empty_i, empty_w = torch.zeros(2, 0, dtype=torch.int64), torch.zeros(0)
     ri = list(g.region_index) + [empty_i] * (mr - regions)
     rw = list(g.region_attr) + [empty_w] * (mr - regions)
-    times = []
-    for it in range(4):                        # first run = warm-up (allocator, thread pool)
-        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-        t0 = time.perf_counter()
-        pred, _ = M.regional_temporal_gcn(q, x, g.edge_index, ri, rw)
-        loss = torch.mean((pred - y) ** 2)
-        loss.backward()
-        if it:
-            times.append(time.perf_counter() - t0)
-        del q, pred, loss
-    dt = statistics.median(times)
-    return {"value": 1.0 / (dt * T * scale_regions), "unit": "snapshots/s", "cores": cores, "kind": "port",
-            "threads": torch.get_num_threads(), **info, "period_s": [round(t, 3) for t in times],
-            "sample": f"1 warm-up + 3 timed runs (median {dt:.2f} s) of 1 of {T} periods (T=1 forward+loss+backward) of "
-                      f"a {nodes}-node/{edges}-edge/{regions}-region graph{note}; periods are independent, "
-                      f"step time = {T}{' x ' + str(scale_regions) if scale_regions > 1 else ''} x period time"}
+
+    def sample(threads, timed):
+        torch.set_num_threads(threads)
+        times = []
+        for it in range(1 + timed):                # first run = warm-up (allocator, thread pool)
+            q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+            t0 = time.perf_counter()
+            pred, _ = M.regional_temporal_gcn(q, x, g.edge_index, ri, rw)
+            loss = torch.mean((pred - y) ** 2)
+            loss.backward()
+            if it:
+                times.append(time.perf_counter() - t0)
+            del q, pred, loss
+        return times
+
+    # The host share of a 1-GPU box is not a given: the same sample is timed with 16 threads (3 timed runs), with min(affinity,
+    # 64) and with min(affinity, 128) threads (2 timed runs each), and the FASTEST setting is the baseline -- all of them are
+    # printed.  (Round 2 fixed 16 threads by assumption; the verdict asked for the measurement.)
+    avail = info["affinity_cpus"]
+    cand = []
+    for th in (min(avail, 16), min(avail, 64), min(avail, 128)):
+        if th not in cand:
+            cand.append(th)
+    runs = {}
+    for i, th in enumerate(cand):
+        ts = sample(th, 3 if i == 0 else 2)
+        runs[th] = {"median_s": round(statistics.median(ts), 3), "period_s": [round(t, 3) for t in ts]}
+    best = min(runs, key=lambda th: runs[th]["median_s"])
+    dt = runs[best]["median_s"]
+    return {"value": 1.0 / (dt * T * scale_regions), "unit": "snapshots/s", "cores": best, "kind": "port",
+            "threads": best, **info, "period_s": runs[best]["period_s"], "by_threads": {str(k): v for k, v in runs.items()},
+            "sample": f"1 warm-up + 2-3 timed runs per thread count {cand} (best: {best} threads, median {dt:.2f} s) of 1 of {T} periods "
+                      f"(T=1 forward+loss+backward) of a {nodes}-node/{edges}-edge/{regions}-region graph{note}; periods are "
+                      f"independent, step time = {T}{' x ' + str(scale_regions) if scale_regions > 1 else ''} x period time"}
 
 
 def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):

@@ -84,7 +84,8 @@ int32_t regt_graph_fingerprint(const int64_t* edge_index, const float* edge_weig
 int32_t regt_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, float* Y,
                       int32_t nrows, int32_t nrows_x, int32_t width, regt_stream_t stream);
 
-/* Both operators in one pass over a merged CSR (two weights per entry): YA = A x, YL = L x; width % 32 == 0. */
+/* Both operators in one pass over a merged CSR (two weights per entry): YA = A x, YL = L x; width % 4 == 0 (widths that are no
+ * multiple of 32 floats -- e.g. the reference's T * F = 48 -- take a whole-row kernel and must not exceed 2048). */
 int32_t regt_spmm_dual(const int32_t* rowptr, const int32_t* col, const float* val_a, const float* val_l, const float* X,
                        float* YA, float* YL, int32_t num_nodes, int32_t width, regt_stream_t stream);
 
@@ -143,7 +144,7 @@ typedef struct regt_graph {
     const int32_t* chunk_region;  /* (n_chunks) */
     int32_t n_chunks;
     /* optional merged operator (N rows): one entry per distinct (row, col) of the two halves above with the
-     * A_hat weight and the L~ weight side by side; when present (and T*F % 32 == 0) both aggregations are
+     * A_hat weight and the L~ weight side by side; when present (and T*F % 32 == 0 or T*F <= 2048) both aggregations are
      * produced by ONE gather pass.  All four NULL = not provided. */
     const int32_t* m_rowptr;      /* (N+1) */
     const int32_t* m_col;

@@ -313,7 +313,9 @@ int check_dims(const regt_dims* d) {
                    d->F, d->C, d->R, d->O, d->H1);
     REGT_CHECK_ARG(d->F % 4 == 0, "dims: F=%d must be a multiple of 4 (16-byte feature rows)", d->F);
     REGT_CHECK_ARG(d->C % 4 == 0, "dims: C=%d must be a multiple of 4", d->C);
-    REGT_CHECK_ARG(d->T <= 64, "dims: T=%d exceeds 64 periods", d->T);
+    // (T <= 64: every element of the hidden state is the sum of at most two partial sums -- bit-reproducible; beyond that a node
+    // spans three or more 64-row blocks and the order of the float atomics shows in the last bits)
+    REGT_CHECK_ARG(d->T <= 255, "dims: T=%d exceeds 255 periods", d->T);
     REGT_CHECK_ARG((long)d->N * d->T < (1L << 31), "dims: N*T too large");
     return REGT_OK;
 }
@@ -465,7 +467,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, N, xp_ext ? x_rows : N, T * F, 1, st));
         else if (g.overlap)
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, (1 + R) * N, xp_ext ? x_rows : N, T * F, 1 + R, st));
-        else if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && (T * F) % 32 == 0)
+        else if (g.m_rowptr && g.m_col && g.m_val_a && g.m_val_l && ((T * F) % 32 == 0 || T * F <= 2048))
             TRY(launch_spmm_dual_x(g.m_rowptr, g.m_col, g.m_val_a, g.m_val_l, Xp, L.AX, L.LX, N, xp_ext ? x_rows : N, T * F, st));
         else
             TRY(launch_spmm_csr(g.rowptr, g.col, g.val, Xp, L.AX, 2 * N, xp_ext ? x_rows : N, T * F, 2, st));
@@ -1192,7 +1194,7 @@ Layout0 make_layout0(const regt_dims& d, int kz, int kh, char* base) {
 }
 int check_cell0(const regt_dims* d, const regt_cell0_args* a) {
     REGT_CHECK_ARG(d && a, "regt_cell0: NULL dims / args");
-    REGT_CHECK_ARG(d->N > 0 && d->T > 0 && d->C > 0 && d->O > 0 && d->H1 > 0 && d->C % 4 == 0 && d->T <= 64, "regt_cell0: bad dims");
+    REGT_CHECK_ARG(d->N > 0 && d->T > 0 && d->C > 0 && d->O > 0 && d->H1 > 0 && d->C % 4 == 0 && d->T <= 255, "regt_cell0: bad dims");
     REGT_CHECK_ARG((long)d->N * d->T < (1L << 31), "regt_cell0: N*T too large");
     REGT_CHECK_ARG(a->kz > 0 && a->kh > 0 && a->a_z && a->a_h && a->gz && a->gh && a->cz && a->ch && a->attention && a->head1_w &&
                    a->head1_b && a->head2_w && a->head2_b, "regt_cell0: a required pointer is NULL");

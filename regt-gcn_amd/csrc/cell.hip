@@ -27,7 +27,7 @@ int launch_softmax_small(const float* att, float* probs, int T, hipStream_t st) 
 //   dhp = g (1-Z) (1-Ht^2)            (candidate pre-activation gradient)
 //   dzp = g (h - Ht) Z (1-Z)          (update-gate pre-activation gradient) -> dzr[:, 0:C]
 //   dp_t += <dOH[node], Z h + (1-Z) Ht>   (attention-probability gradient; fixed-order partial sums)
-constexpr int CB_MAXT = 64;
+constexpr int CB_MAXT = 255;     // periods per snapshot (the row tables of the candidate kernels keep the period in 8 bits)
 // four fp32 -> four bf16 (round to nearest even), one 8-byte store at bf16 element index `elem`
 __device__ __forceinline__ void store_bf16x4(void* base, long elem, float4 v) {
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));

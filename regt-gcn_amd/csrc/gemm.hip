@@ -1464,7 +1464,7 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
         if (int rc = set_lds_once(&gemm_cand_flat_kernel<SplitCore<false, 1>>, G_FAST_LDS_BYTES, &attr_done_bf16)) return rc;
         const long M = (long)a.num_nodes * a.T;
         const long ftiles = (long)cdiv(M, GBM) * cdiv(a.C, GBN);
-        REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 64, "candidate gemm: too many tiles / T > 64");
+        REGT_CHECK_ARG(ftiles < (1L << 31) && a.T <= 255, "candidate gemm: too many tiles / T > 255");
         if (int rc = launch_zero_f32(a.OH, (long)a.num_nodes * a.C, st)) return rc;
         // three-workgroup kernels (fp32 storage): 64-row halves need T <= 64 (a node meets at most two halves)
         const bool three = !a.act_bf16 && !fp32_core_wide() && gemm_mode() != 2 && (gemm_mode() == 1 || ftiles >= SMALL_TILE_LIMIT) && M < (1L << 31);

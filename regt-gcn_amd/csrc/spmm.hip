@@ -147,6 +147,51 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const int* __restrict__ r
     }
 }
 
+// The same row-per-lane-group pull with the MERGED operator (two weights per entry, both outputs from one gather): rows of any
+// width that is a multiple of 4 floats -- the case the panel kernels (whole 128-byte panels, W % 32 == 0) do not cover, e.g. the
+// reference's own TPIMS widths T * F = 48 and 96.  Small graphs only (X lives in the L2s), so no panel schedule is needed.
+template <int G, int CH>
+__global__ __launch_bounds__(256) void spmm_dual_csr_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                            const float* __restrict__ val_a, const float* __restrict__ val_l,
+                                                            const float* __restrict__ X, float* __restrict__ YA, float* __restrict__ YL,
+                                                            int nrows, int W4) {
+    constexpr int GROUPS = 256 / G;
+    const int gl = threadIdx.x % G, gid = threadIdx.x / G;
+    const long W = (long)W4 * 4;
+    for (long row = (long)blockIdx.x * GROUPS + gid; row < nrows; row += (long)gridDim.x * GROUPS) {
+        float4 aa[CH], al[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) aa[c] = al[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        for (int base = beg; base < end; base += G) {
+            const int n = end - base < G ? end - base : G;
+            int myc = 0;
+            float mya = 0.f, myl = 0.f;
+            if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+            for (int e = 0; e < n; ++e) {
+                const int c0 = __shfl(myc, e, G);
+                const float va = __shfl(mya, e, G), vl = __shfl(myl, e, G);
+                const float4* x0 = reinterpret_cast<const float4*>(X + (long)c0 * W);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int ch = gl + c * G;
+                    const float4 a = ch < W4 ? x0[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    aa[c].x = fmaf(va, a.x, aa[c].x); aa[c].y = fmaf(va, a.y, aa[c].y); aa[c].z = fmaf(va, a.z, aa[c].z); aa[c].w = fmaf(va, a.w, aa[c].w);
+                    al[c].x = fmaf(vl, a.x, al[c].x); al[c].y = fmaf(vl, a.y, al[c].y); al[c].z = fmaf(vl, a.z, al[c].z); al[c].w = fmaf(vl, a.w, al[c].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ch = gl + c * G;
+            if (ch < W4) {
+                reinterpret_cast<float4*>(YA + row * W)[ch] = aa[c];
+                reinterpret_cast<float4*>(YL + row * W)[ch] = al[c];
+            }
+        }
+    }
+}
+
 // ---- XCD-aware column-panel variant (large graphs) --------------------------------------------------
 // The plain kernel above re-reads every neighbour row from the Infinity Cache: X (N*W*4 B, 154 MB at
 // cfg-3) does not fit the 4 MiB L2 of an XCD, so the gather traffic is nnz*W*4 B (3.1 GB) and the
@@ -534,8 +579,30 @@ int launch_spmm_dual(const int* rowptr, const int* col, const float* val_a, cons
 
 int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, const float* val_l, const float* X, float* YA,
                        float* YL, int nnodes, int x_rows, int W, hipStream_t st) {
-    REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 32 == 0, "spmm_dual: width %d must be a multiple of 32 floats", W);
+    REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 4 == 0, "spmm_dual: width %d must be a multiple of 4 floats", W);
     const int W4 = W / 4;
+    if (W % 32 != 0 || ((long)x_rows * W * 4 <= (24L << 20) && W4 <= 512)) {
+        // rows that are not whole 128-byte panels, or an X that lives in the L2s anyway: one lane group per row, whole rows
+        REGT_CHECK_ARG(W4 <= 512, "spmm_dual: width %d is neither a multiple of 32 floats nor at most 2048", W);
+        long blocks;
+#define REGT_DUALCSR(G, CH)                                                                                                     \
+    do {                                                                                                                       \
+        blocks = ((long)nnodes + 256 / G - 1) / (256 / G);                                                                     \
+        if (blocks > 256L * 64) blocks = 256L * 64;                                                                            \
+        hipLaunchKernelGGL((spmm_dual_csr_kernel<G, CH>), dim3((unsigned)blocks), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL, \
+                           nnodes, W4);                                                                                        \
+    } while (0)
+        if (W4 <= 8) REGT_DUALCSR(8, 1);
+        else if (W4 <= 16) REGT_DUALCSR(16, 1);
+        else if (W4 <= 32) REGT_DUALCSR(32, 1);
+        else if (W4 <= 64) REGT_DUALCSR(64, 1);
+        else if (W4 <= 128) REGT_DUALCSR(64, 2);
+        else if (W4 <= 256) REGT_DUALCSR(64, 4);
+        else REGT_DUALCSR(64, 8);
+#undef REGT_DUALCSR
+        REGT_CHECK_LAUNCH();
+        return REGT_OK;
+    }
     {
         static int pl_env0 = -1;
         if (pl_env0 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env0 = e ? atoi(e) : 0; }

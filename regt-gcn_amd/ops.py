@@ -77,7 +77,7 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, x: torc
 
 
 def spmm_dual(rowptr, col, val_a, val_l, x: torch.Tensor):
-    """(A x, L x) from the merged two-weight CSR in one gather pass; x.shape[1] % 32 == 0."""
+    """(A x, L x) from the merged two-weight CSR in one gather pass; x.shape[1] % 4 == 0."""
     x = _f32c(x, "x")
     n = rowptr.numel() - 1
     ya = torch.empty(n, x.shape[1], dtype=torch.float32, device=x.device)

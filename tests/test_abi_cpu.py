@@ -75,9 +75,9 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     g.rowptr = g.col = g.val = g.node_region = 256
     rc = lib.regt_forward(B(good), B(g), B(p), one, one, one, one, 1 << 30, None)
     assert rc != 0 and b"required tensor pointer is NULL" in lib.regt_last_error()
-    bad_t = _lib.Dims(104, 65, 8, 256, 5, 1, 128, 1, 0.01)
+    bad_t = _lib.Dims(104, 256, 8, 256, 5, 1, 128, 1, 0.01)
     rc = lib.regt_forward(B(bad_t), B(g), B(p), one, one, one, one, 1 << 30, None)
-    assert rc != 0 and b"exceeds 64 periods" in lib.regt_last_error()
+    assert rc != 0 and b"exceeds 255 periods" in lib.regt_last_error()
     rc = lib.regt_cell_forward(B(good), B(g), B(p), one, one, one, one, one, 1 << 30, None)
     assert rc != 0 and b"regional must be 0" in lib.regt_last_error()
     rc = lib.regt_backward(B(good), B(g), B(p), None, one, None, one, None, one, 1 << 30, None)
