@@ -761,9 +761,15 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         PROF("dgrad_gates", st);
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
     }
+    // The (C x F)-sized gradients (Gh, Gzr, A0 | A_r) are HBM-bound -- they stream dhp / dzp|drp / ds for a K = F..2F product --
+    // while the two big ones (Uh, Uzr) sit on the matrix pipe: REGT_SIDE_WGRADS=1 issues the former on the side stream so that
+    // the two kinds overlap (A/B switch; see DESIGN.md section 6 for the measurement).
+    static int side_wgrads = -1;
+    if (side_wgrads < 0) { const char* e = getenv("REGT_SIDE_WGRADS"); side_wgrads = e ? atoi(e) : 0; }
+    hipStream_t sw = side_wgrads ? side_fork(st) : st;
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
     TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
-    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, st, ibf, xbf));
+    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
     {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
         a.p_bf16 = ibf; a.q_bf16 = abf;
@@ -784,7 +790,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // (One launch per pair with a two-part right-hand side [q | A_hat x] / [h | A_hat x] -- so that dhp and dzp|drp are read
     // once -- was measured and is slower: 1.86 vs 1.44 ms for the four at the cfg-5 shard; the third, half-empty column tile and
     // the doubled load instructions of the two-descriptor staging cost more than the second pass over the left operand.)
-    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, st, ibf, xbf));
+    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, sw, ibf, xbf));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;
@@ -798,8 +804,8 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         a.p_bf16 = abf; a.q_bf16 = xbf;
         TRY(rq.take((long)g.n_chunks * wgrad_slab_stride(a), &a.slab));
         {
-            PROF("wgrad_A0_Ar", st);
-            TRY(launch_wgrad(a, st));
+            PROF("wgrad_A0_Ar", sw);
+            TRY(launch_wgrad(a, sw));
         }
         WgradReduceArgs r0{};
         r0.slab = a.slab; r0.nchunks = g.n_chunks; r0.slab_stride = wgrad_slab_stride(a); r0.elem_offset = 0; r0.slab_ld = 2 * F;
