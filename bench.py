@@ -248,6 +248,8 @@ def cfg5shard_leg(args):
 def stage_flops(stage, M, C, F):
     if stage == "fused_forward":        # regional embedding + gates + candidate in one kernel (bf16 arithmetic, csrc/fused.hip)
         return 2.0 * M * (C * 2 * F + 2 * C * (C + F) + C * (C + F))
+    if stage == "fused_backward":       # cell_bwd + dgrad_candidate + dgrad_gates in one kernel (bf16 arithmetic, csrc/fused.hip)
+        return 2.0 * M * 3 * C * C
     return {
         "gemm_gates": 2.0 * M * 2 * C * (C + F), "gemm_candidate": 2.0 * M * C * (C + F),
         "gemm_regional": 2.0 * M * C * 2 * F, "dgrad_candidate": 2.0 * M * C * C, "dgrad_gates": 2.0 * M * C * 2 * C,
@@ -268,6 +270,7 @@ def stage_bytes(stage, M, C, F, mode=0, xbf=False):
         "gemm_candidate": a * C + x * F + a * C + a * C + a * C,    # read q, A_hat x, Z, h; write H~
         "gemm_regional": x * 2 * F + a * C,                         # read x, L~ x; write h
         "fused_forward": x * 3 * F + a * 5 * C,                     # read x, L~ x, A_hat x; write h, [Z|R], q, H~ -- nothing read back
+        "fused_backward": a * 4 * C + a * 4 * C,                    # read Z, R, h, H~; write dhp, dzp, drp, ds
         "cell_bwd": a * 3 * C + a * 2 * C,                          # read Z, h, H~; write dhp, dzp
         "dgrad_candidate": a * (C + C + 2 * C) + a * 2 * C,         # read dhp, h, Z, R; write drp, dh
         "dgrad_gates": a * (2 * C + C + C) + a * C,                 # read dzp|drp, dh, h; write ds
@@ -291,6 +294,8 @@ def stage_kernel(stage, mode):
         return pats
     if stage == "fused_forward":
         return ["fused_fwd_kernel"]
+    if stage == "fused_backward":
+        return ["fused_bwd_kernel"]
     if stage == "gemm_candidate":
         return {0: ["gemm_cand_split_kernel<0>", "gemm_cand_flat_kernel<regt::FastCore"],
                 1: ["gemm_cand_split_kernel<3>", "gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
@@ -497,7 +502,7 @@ def main():
     # Secondary, opt-in arithmetics (never the headline): the same K steps in the other GEMM modes.  N = 1 only, after the
     # timed region.
     other_modes = {}
-    if world == 1 and not args.no_split_leg and not force_shard:
+    if world == 1 and not args.no_split_leg and not force_shard and not rows_bf16:     # (bf16 input rows exist in mode 2 only)
         for m2 in (1, 2):
             if m2 == mode:
                 continue

@@ -161,6 +161,11 @@ int q_format(const void* ws) {
 // ... and, where the fused forward kernel applies (fused.hip: C = 256, F = 64, node-disjoint regions), x, A_hat x and L~ x as
 // well: the snapshot is rounded once while it is packed, the aggregation reads and writes bf16 rows (cfg-5).
 // REGT_XBF=0 keeps them fp32 and the three-launch forward (A/B timing; tests/test_gpu_fused.py compares the two bit for bit).
+int g_opt_fused_bwd = -1;
+bool fused_bwd_wanted() {
+    if (g_opt_fused_bwd < 0) { const char* e = getenv("REGT_FUSED_BWD"); g_opt_fused_bwd = e ? atoi(e) : 1; }
+    return g_opt_fused_bwd != 0;
+}
 int g_opt_xbf = -1;
 bool xbf_wanted() {
     if (g_opt_xbf < 0) { const char* e = getenv("REGT_XBF"); g_opt_xbf = e ? atoi(e) : 1; }
@@ -223,7 +228,7 @@ struct Layout {
     float *S;    // (C, C): sum of the region blocks of tgnn.linear.weight (forward, reused by backward)
     float *G0;   // (C, C): the part of d tgnn.linear.weight every region block shares (backward)
     // backward temporaries
-    float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *slab;
+    float *dOH, *d1, *dhp, *dzr, *dh, *dp_partial, *rowdot, *slab;
     float *UT;   // (3, C, C): transposed H-halves of the gate weights (h, z, r) for the data-gradient GEMMs
     float *Wb;   // fragment-order bf16 copies of the GEMM weights (bf16 mode)
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
@@ -285,6 +290,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.cb_npb = (L.cb_npb + 3) / 4 * 4;
     L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
     L.dp_partial = take((long)L.cb_blocks * T);
+    L.rowdot = take(M);                               // per-row <dOH, H'> of the fused backward kernel (fused.hip)
     // one slab region per weight gradient (their reductions are deferred into one launch, ReduceQueue): the sum of
     // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
     long slab = (long)L.nchunks * (C * C + C) + (long)L.nchunks * (2 * C * C + 2 * C)
@@ -704,14 +710,6 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // ---- head ----------------------------------------------------------------------------------
     ReduceQueue rq(L.slab, L.slab_floats, st);
     TRY(head_backward(d, p, gr, dpred, dhidden, hidden, L.y1, L.d1, L.dOH, L.kchunk_head, L.nchunks_head, rq, st));
-    // ---- cell: gate pre-activation gradients ------------------------------------------------------
-    {
-        CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
-        a.out_bf16 = ibf; a.in_bf16 = abf;
-        PROF("cell_bwd", st);
-        TRY(launch_cell_bwd(a, st));
-        if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
-    }
     // The three-workgroup cores (gemm_split.h: fp32 planes, bf16x3 split, bf16) take weights as [N][K] only: give the data
     // gradients transposed copies of the three C x C blocks.  REGT_FP32_CORE=wide keeps the fp32 path on the two-workgroup
     // core, which reads the weights as they are.
@@ -729,6 +727,32 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         PROF("weights_bf16", st);
         TRY(launch_cvt_bf16_frag(cb, st));
     }
+    // bf16 arithmetic with fragment-order weights: the three data-gradient launches below as ONE kernel (fused.hip), every
+    // activation read and written once.  Same results bit for bit except the summation order of the attention gradient.
+    const bool fused = wfr && !h_ext && fused_backward_ok(C) && fused_bwd_wanted();
+    if (fused) {
+        FusedBwdArgs a{};
+        a.ZR = L.ZR; a.h = H; a.Ht = L.Ht; a.dOH = L.dOH; a.probs = L.probs;
+        a.UhTf = wb.UT[0]; a.UzTf = wb.UT[1]; a.UrTf = wb.UT[2];
+        a.dhp = L.dhp; a.dzr = L.dzr; a.dh = DH; a.rowdot = L.rowdot;
+        a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = d.regional ? 1 : 0;
+        {
+            PROF("fused_backward", st);
+            TRY(launch_fused_backward(a, C, st));
+        }
+        if (gr.attention) {
+            TRY(launch_rowdot_reduce(L.rowdot, L.dp_partial, N, T, L.cb_npb, st));
+            TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
+        }
+    } else {
+    // ---- cell: gate pre-activation gradients ------------------------------------------------------
+    {
+        CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
+        a.out_bf16 = ibf; a.in_bf16 = abf;
+        PROF("cell_bwd", st);
+        TRY(launch_cell_bwd(a, st));
+        if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
+    }
     {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
         GemmSegs S{};
         S.nseg = 1;
@@ -744,9 +768,9 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
         GemmSegs S{};
         S.nseg = 2;
-        if (wfr) {
-            S.seg[0] = make_seg(L.dzr, 2L * C, wb.UT[1], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
-            S.seg[1] = make_seg(byte_off(L.dzr, 2L * C), 2L * C, wb.UT[2], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
+        if (wfr) {      // (drp first: the accumulation order of the fused kernel, which multiplies drp while dzp is still on its way)
+            S.seg[0] = make_seg(byte_off(L.dzr, 2L * C), 2L * C, wb.UT[2], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
+            S.seg[1] = make_seg(L.dzr, 2L * C, wb.UT[1], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
         } else if (split) {
             const int fl = ibf ? SEG_A_BF16 : 0;
             S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true, fl);
@@ -760,6 +784,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         e.h_bf16 = abf; e.dh_bf16 = abf;
         PROF("dgrad_gates", st);
         TRY(launch_gemm_dgrad2(S, M, C, e, st));
+    }
     }
     // The (C x F)-sized gradients (Gh, Gzr, A0 | A_r) are HBM-bound -- they stream dhp / dzp|drp / ds for a K = F..2F product --
     // while the two big ones (Uh, Uzr) sit on the matrix pipe: REGT_SIDE_WGRADS=1 issues the former on the side stream so that
@@ -922,6 +947,7 @@ const char* regt_last_error(void) { return g_err; }
 int32_t regt_set_option(const char* name, int32_t value) {
     REGT_CHECK_ARG(name != nullptr, "regt_set_option: name is NULL");
     if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
+    if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     set_error("regt_set_option: unknown option '%s'", name);
     return -1;

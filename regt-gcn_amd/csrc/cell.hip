@@ -140,9 +140,9 @@ __global__ __launch_bounds__(256) void cell_bwd8_kernel(CellBwdArgs a) {
                     }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const float g = pt * dd[k];
-                        dhp[k] = g * (1.0f - z[k]) * (1.0f - ht[k] * ht[k]);
-                        dzp[k] = g * (h[k] - ht[k]) * (z[k] * (1.0f - z[k]));
+                        const float g = __fmul_rn(pt, dd[k]);
+                        dhp[k] = cb_dhp(g, z[k], ht[k]);
+                        dzp[k] = cb_dzp(g, h[k], ht[k], z[k]);
                         dot += dd[k] * (z[k] * h[k] + (1.0f - z[k]) * ht[k]);
                     }
                     *reinterpret_cast<uint4*>(Pb + 2 * (m * C + 8 * c8)) = narrow8(dhp);
@@ -160,6 +160,34 @@ __global__ __launch_bounds__(256) void cell_bwd8_kernel(CellBwdArgs a) {
 }
 
 int cell_bwd_blocks(int num_nodes, int nodes_per_block) { return cdiv(num_nodes, nodes_per_block); }
+
+// Attention-probability partial sums from the per-row dots the fused backward kernel leaves behind: block b owns
+// nodes_per_block consecutive nodes; thread (g, t) adds rowdot[node * T + t] for the nodes n0 + g, n0 + g + G, ... (ascending),
+// thread t then adds the G group sums in order -- a fixed summation order, like cell_bwd_kernel's.
+__global__ __launch_bounds__(256) void rowdot_reduce_kernel(const float* __restrict__ rowdot, float* __restrict__ dp_partial,
+                                                            int num_nodes, int T, int nodes_per_block) {
+    __shared__ float part[256];
+    const int G = 256 / T, g = threadIdx.x / T, t = threadIdx.x - g * T;
+    const int n0 = blockIdx.x * nodes_per_block;
+    const int n1 = n0 + nodes_per_block < num_nodes ? n0 + nodes_per_block : num_nodes;
+    float s = 0.f;
+    if (g < G)
+        for (int node = n0 + g; node < n1; node += G) s += rowdot[(long)node * T + t];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < T) {
+        float acc = 0.f;
+        for (int k = 0; k < G; ++k) acc += part[k * T + threadIdx.x];
+        dp_partial[(long)blockIdx.x * T + threadIdx.x] = acc;
+    }
+}
+int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st) {
+    REGT_CHECK_ARG(T >= 1 && T <= CB_MAXT, "rowdot_reduce: T=%d outside 1..%d", T, CB_MAXT);
+    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3(cell_bwd_blocks(num_nodes, nodes_per_block)), dim3(256), 0, st, rowdot, dp_partial,
+                       num_nodes, T, nodes_per_block);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
 
 // Zero-hidden cell (the reference's GraphSAGE / GAT models call the cell with H = None -> zeros, models/utils.py:163-166):
 // H' = Z * 0 + (1 - Z) * H~, summed over the T periods with the attention probabilities.  One wave per node, lanes over C.

@@ -404,6 +404,274 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #undef FT_MARK
 }
 
+// ---- fused data gradients of the cell ---------------------------------------------------------------------------------------------
+// cell_bwd + dgrad_candidate + dgrad_gates of the three-launch backward in one kernel per 64-row tile.  With g = p_t dOH[node]:
+//     dhp = g (1 - Z) (1 - H~^2),   dzp = g (h - H~) Z (1 - Z)                       (gate pre-activation gradients: cell.hip)
+//     dq  = dhp Uh2,   drp = dq h R (1 - R),   dh = dq R + g Z                        (back through linear_h's h-half and q = h R)
+//     ds  = (dh + dzp Uz2 + drp Ur2) act'(h)                                          (back through linear_z / _r, into the embedding)
+// i.e. the transposes of models/utils.py:168-188 in the composed form of DESIGN.md section 3.  The three launches read Z (twice),
+// R, h (three times), H~, dhp, [dzp|drp] and dh back from HBM: 11 activation reads + 5 writes of M x C bf16 per step; here Z, R, h,
+// H~ are read and dhp, dzp, drp, ds written once (h, Z and dOH are read a second time in the dq epilogue, from L2 / MALL).
+// Same tile shape, fragment loads, plane layout and wave-private epilogue images as the forward kernel above: dhp is the A operand of
+// the dq product (planes P), drp fills planes R from the dq epilogues, dzp is fetched back (L2) while drp Ur2 runs and takes dhp's
+// place in P; ds accumulates drp Ur2 + dzp Uz2 in one K = 2C loop (the order of the three-launch kernel), dh makes the same round
+// trip through its bf16 array as in the three-launch path (same lane writes and reads it: L2).  Bit-identical to the three launches except for the summation order of
+// the attention-probability gradient (per-row dots -> rowdot, summed in a fixed order by rowdot_reduce_kernel).
+template <int C>
+struct FusedBwdLds {
+    static constexpr int PLANE_B = FT_ROWS * 32;
+    static constexpr int OPER_B = (C / 16) * PLANE_B;
+    static constexpr int IMG_OFF = 2 * OPER_B;
+    static constexpr int DOT_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
+    static constexpr int BYTES = DOT_OFF + 4 * FT_ROWS * 4;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
+    static_assert(C % 128 == 0, "tile shapes");
+    using L = FusedBwdLds<C>;
+    constexpr int KBC = C / 16, NT = C / 128;
+    extern __shared__ __attribute__((aligned(16))) char flds[];
+    char* Pp = flds;                         // dhp, later dzp
+    char* Rp = flds + L::OPER_B;             // drp
+    const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long m0 = (long)blockIdx.x * FT_ROWS;
+    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+    const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;
+    const unsigned node0 = mrow0 / uT;
+    const long nodes = a.M / a.T;
+    // the tile's rows of every activation array; dOH from the tile's first node on (rows past the end read zeros, stores are dropped)
+    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<const char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
+    const __amdgpu_buffer_rsrc_t sH = f_rsrc(reinterpret_cast<const char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<const char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sD = f_rsrc(a.dOH + (long)node0 * C, (nodes - (long)node0) * C * 4);
+    const __amdgpu_buffer_rsrc_t sdhp = f_rsrc(reinterpret_cast<char*>(a.dhp) + m0 * C * 2, (long)nvalid * C * 2);
+    const __amdgpu_buffer_rsrc_t sdzr = f_rsrc(reinterpret_cast<char*>(a.dzr) + m0 * C * 4, (long)nvalid * C * 4);
+    const __amdgpu_buffer_rsrc_t sdh = f_rsrc(reinterpret_cast<char*>(a.dh) + m0 * C * 2, (long)nvalid * C * 2);
+
+    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
+    float* dotw = reinterpret_cast<float*>(flds + L::DOT_OFF);
+    const int er = lane >> 2, ec = 32 * w + 8 * (lane & 3);     // the lane's epilogue row of a round / first of its 8 columns of a tile
+    float pt_[4];                                                // per round: attention probability of the lane's row,
+    int dof_[4];                                                 //   byte offset of its node's dOH row behind node0's
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {
+        const unsigned m = mrow0 + 16 * rnd + er, nd = m / uT;
+        pt_[rnd] = a.probs[m - nd * uT];
+        dof_[rnd] = (int)(nd - node0) * C * 4;
+    }
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {
+        const int mi = rnd >> 1, rd = rnd & 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
+            imgw[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + lr] = mi ? acc[1][reg] : acc[0][reg];
+        }
+    };
+    auto img8 = [&]() {
+        const float4* p = reinterpret_cast<const float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
+        const float4 lo = p[0], hi = p[1];
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
+    auto ldd8 = [&](int off) {
+        const u32x4_t lo = __builtin_amdgcn_raw_buffer_load_b128(sD, off, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b128(sD, off + 16, 0, 0);
+        return V8{{__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w),
+                   __uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w)}};
+    };
+    // B fragments of one K = C product: column block nb of a transposed C x C weight block in fragment order
+    bf16x8 bw[KBC];
+    auto issue_b = [&](const void* Wf, int nb, int from, int to) {
+        const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2);
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb)
+            if (kb >= from && kb < to) bw[kb] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
+    };
+    // acc (+)= P (planes, K = C) x W^T with the fragments in bw; `Wnext` != nullptr: the two halves of bw are refilled with the
+    // fragments of (Wnext, nbnext) as soon as they have been multiplied (the second product of a K = 2C loop)
+    auto kloop = [&](f32x16 (&acc)[2], const char* P, bool zero, const void* Wnext, int nbnext) {
+        if (zero) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        }
+        const char* pa0 = P + sp_off(lr, lh);
+        const char* pa1 = P + sp_off(32 + lr, lh);
+        constexpr int AHEAD = 3;
+        bf16x8 fa[KBC + AHEAD][2];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < AHEAD; ++kb) {
+            fa[kb][0] = *reinterpret_cast<const bf16x8*>(pa0 + kb * L::PLANE_B);
+            fa[kb][1] = *reinterpret_cast<const bf16x8*>(pa1 + kb * L::PLANE_B);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < KBC; ++kb) {
+            if (kb + AHEAD < KBC) {
+                fa[kb + AHEAD][0] = *reinterpret_cast<const bf16x8*>(pa0 + (kb + AHEAD) * L::PLANE_B);
+                fa[kb + AHEAD][1] = *reinterpret_cast<const bf16x8*>(pa1 + (kb + AHEAD) * L::PLANE_B);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], bw[kb], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], bw[kb], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (Wnext && kb == KBC / 2 - 1) { issue_b(Wnext, nbnext, 0, KBC / 2); __builtin_amdgcn_sched_barrier(0); }
+            if (Wnext && kb == KBC - 1) { issue_b(Wnext, nbnext, KBC / 2, KBC); __builtin_amdgcn_sched_barrier(0); }
+        }
+    };
+
+    // ---- phase A: gate pre-activation gradients (element-wise): dhp -> global + planes P, dzp -> global ----------------------------
+    float rdot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        u32x4_t zr_[4], hr_[4], tr_[4];
+        V8 dd_[4];
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            zr_[rnd] = ld16(sZR, (row * 2 * C + c) * 2);
+            hr_[rnd] = ld16(sH, (row * C + c) * 2);
+            tr_[rnd] = ld16(sHt, (row * C + c) * 2);
+            dd_[rnd] = ldd8(dof_[rnd] + c * 4);
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            const V8 z = f_widen8(zr_[rnd]), h = f_widen8(hr_[rnd]), ht = f_widen8(tr_[rnd]);
+            V8 dhp, dzp;
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float g = __fmul_rn(pt_[rnd], dd_[rnd].v[i]);
+                dhp.v[i] = cb_dhp(g, z.v[i], ht.v[i]);
+                dzp.v[i] = cb_dzp(g, h.v[i], ht.v[i], z.v[i]);
+                dot += dd_[rnd].v[i] * (z.v[i] * h.v[i] + (1.0f - z.v[i]) * ht.v[i]);
+            }
+            rdot[rnd] += dot;
+            const u32x4_t pk = f_pack8(dhp);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, sdhp, (row * C + c) * 2, 0, 0);
+            *reinterpret_cast<u32x4_t*>(Pp + plane_off(row, c)) = pk;
+            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(dzp), sdzr, (row * 2 * C + c) * 2, 0, 0);
+        }
+    }
+    issue_b(a.UhTf, w, 0, KBC);                                  // dq, column tile 0
+#pragma unroll
+    for (int rnd = 0; rnd < 4; ++rnd) {                          // the wave's 32 columns x 2 tiles of row 16 rnd + er
+        float s = rdot[rnd];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((lane & 3) == 0) dotw[w * FT_ROWS + 16 * rnd + er] = s;
+    }
+    __syncthreads();                                            // planes P (dhp) and the four waves' row dots complete
+    if (tid < nvalid) a.rowdot[m0 + tid] = (dotw[tid] + dotw[FT_ROWS + tid]) + (dotw[2 * FT_ROWS + tid] + dotw[3 * FT_ROWS + tid]);
+
+    // ---- phase B: dq = dhp Uh2 per column tile; drp -> global + planes R, dh -> global (bf16: read back by the same lane in phase D,
+    //      which is exactly the rounding point of the three-launch path) ----------------------------------------------------------------
+    static_assert(NT == 2, "h-sign masks of two column tiles");
+    unsigned hpos0 = 0, hpos1 = 0;                               // bit 8 rnd + i: h > 0 (the leaky-relu derivative of phase D)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        unsigned hp = 0;
+        u32x4_t xh[2], xz[2], xr[2];                             // operands of the epilogue rounds, requested one round ahead
+        V8 xd[2];
+        auto aux = [&](int rnd) {
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            xh[rnd & 1] = ld16(sH, (row * C + c) * 2);
+            xz[rnd & 1] = ld16(sZR, (row * 2 * C + c) * 2);
+            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);
+            xd[rnd & 1] = ldd8(dof_[rnd] + c * 4);
+        };
+        aux(0);
+        f32x16 acc[2];
+        kloop(acc, Pp, true, nullptr, 0);
+        if (j + 1 < NT) issue_b(a.UhTf, 4 * (j + 1) + w, 0, KBC);
+        else issue_b(a.UrTf, w, 0, KBC);                         // ds, column tile 0, first product
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            if (rnd + 1 < 4) aux(rnd + 1);
+            stage(acc, rnd);
+            const V8 v = img8();
+            const int row = 16 * rnd + er, c = 128 * j + ec;
+            const V8 h = f_widen8(xh[rnd & 1]), Z = f_widen8(xz[rnd & 1]), R = f_widen8(xr[rnd & 1]);
+            V8 drp, dh;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                drp.v[i] = cb_drp(v.v[i], h.v[i], R.v[i]);
+                dh.v[i] = cb_dh(v.v[i], R.v[i], pt_[rnd], xd[rnd & 1].v[i], Z.v[i]);
+                hp |= (h.v[i] > 0.f ? 1u : 0u) << (8 * rnd + i);
+            }
+            const u32x4_t pr = f_pack8(drp);
+            __builtin_amdgcn_raw_buffer_store_b128(pr, sdzr, (row * 2 * C + C + c) * 2, 0, 0);
+            *reinterpret_cast<u32x4_t*>(Rp + plane_off(row, c)) = pr;
+            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(dh), sdh, (row * C + c) * 2, 0, 0);
+        }
+        if (j == 0) hpos0 = hp;
+        else hpos1 = hp;
+    }
+    __syncthreads();                                            // planes R (drp) complete, every wave is done with dhp in planes P
+
+    // ---- phase D: ds = (dh + drp Ur2 + dzp Uz2) act'(h) per column tile -> global.  dzp comes back from global memory (the lane's own
+    //      stores of phase A) while the first product runs, and takes dhp's place in planes P --------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        u32x4_t dhr[4], dzk[NT][4];
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) dhr[rnd] = ld16(sdh, ((16 * rnd + er) * C + 128 * j + ec) * 2);
+        if (j == 0) {
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+                for (int rnd = 0; rnd < 4; ++rnd) dzk[jj][rnd] = ld16(sdzr, ((16 * rnd + er) * 2 * C + 128 * jj + ec) * 2);
+        }
+        f32x16 acc[2];
+        kloop(acc, Rp, true, a.UzTf, 4 * j + w);
+        if (j == 0) {
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+                for (int rnd = 0; rnd < 4; ++rnd) *reinterpret_cast<u32x4_t*>(Pp + plane_off(16 * rnd + er, 128 * jj + ec)) = dzk[jj][rnd];
+            __syncthreads();                                    // planes P (dzp) complete
+        }
+        kloop(acc, Pp, false, nullptr, 0);
+        if (j + 1 < NT) issue_b(a.UrTf, 4 * (j + 1) + w, 0, KBC);
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            stage(acc, rnd);
+            const V8 v = img8();
+            const V8 d = f_widen8(dhr[rnd]);
+            V8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool pos = ((j ? hpos1 : hpos0) >> (8 * rnd + i)) & 1u;
+                o.v[i] = cb_ds(d.v[i], v.v[i], (a.act_lrelu && !pos) ? a.slope : 1.0f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(o), sdh, ((16 * rnd + er) * C + 128 * j + ec) * 2, 0, 0);
+        }
+    }
+}
+
+int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st) {
+    REGT_CHECK_ARG(a.M > 0 && a.T > 0 && a.M % a.T == 0, "fused backward: empty problem");
+    REGT_CHECK_ARG(C == 256, "fused backward: built for C = 256 (got C = %d)", C);
+    const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
+    REGT_CHECK_ARG(tiles < (1L << 31) && a.M < (1L << 31), "fused backward: too many rows");
+    using L = FusedBwdLds<256>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((fused_bwd_kernel<256>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
+}
+bool fused_backward_ok(int C) { return C == 256; }
+
 static long* g_fused_trace = nullptr;
 static long g_fused_trace_n = 0;
 // copies the stamps of the last traced launch to the host (synchronises); returns the number of values

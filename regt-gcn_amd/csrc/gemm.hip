@@ -557,10 +557,10 @@ struct EpiDgrad18F {
         return a;
     }
     __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux&, const Aux& a) const {
-#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+#define F_(k) cb_drp(v.k, a.h.k, a.R.k)
         st8(e.dzr, m * (2L * e.C) + e.C + c, REGT_F8(F_), e.dzr_bf16);
 #undef F_
-#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+#define F_(k) cb_dh(v.k, a.R.k, a.p, a.d.k, a.Z.k)
         st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
 #undef F_
     }
@@ -605,10 +605,10 @@ struct EpiDgrad18F {
     }
     template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, const F8& v, const Col&, const VAux& a) const {
         const F8 h = widen8(a.h), Z = widen8(a.Z), R = widen8(a.R), d = F8{a.d0, a.d1};
-#define F_(k) (v.k * h.k * (R.k * (1.0f - R.k)))
+#define F_(k) cb_drp(v.k, h.k, R.k)
         buf_st8_bf16(t.dzr, t.vzr + i * t.szr, REGT_F8(F_));
 #undef F_
-#define F_(k) (v.k * R.k + a.p * d.k * Z.k)
+#define F_(k) cb_dh(v.k, R.k, a.p, d.k, Z.k)
         buf_st8_bf16(t.dh, t.vc + i * t.sc, REGT_F8(F_));
 #undef F_
     }
@@ -628,7 +628,7 @@ struct EpiDgrad28F {
         return a;
     }
     __device__ __forceinline__ void apply(long m, int c, const F8& v, const ColAux&, const Aux& a) const {
-#define F_(k) ((a.d.k + v.k) * (a.h.k > 0.f ? 1.0f : e.slope))
+#define F_(k) cb_ds(a.d.k, v.k, a.h.k > 0.f ? 1.0f : e.slope)
         st8(e.dh, m * e.C + c, REGT_F8(F_), e.dh_bf16);
 #undef F_
     }
@@ -658,7 +658,7 @@ struct EpiDgrad28F {
         const F8 d = widen8(a.d);
         F8 h = d;
         if (V & 1) h = widen8(a.h);
-#define F_(k) ((d.k + v.k) * ((V & 1) ? (h.k > 0.f ? 1.0f : e.slope) : 1.0f))
+#define F_(k) cb_ds(d.k, v.k, (V & 1) ? (h.k > 0.f ? 1.0f : e.slope) : 1.0f)
         buf_st8_bf16(t.dh, t.v + i * t.s, REGT_F8(F_));
 #undef F_
     }

@@ -50,6 +50,15 @@ __device__ __forceinline__ void buf_st4_bf16(__amdgpu_buffer_rsrc_t r, int voff,
 // wherever it is computed (candidate epilogues in gemm.hip, fused forward in fused.hip): left to -ffp-contract the two
 // kernels could round differently, and tests/test_gpu_fused.py compares them bit for bit.
 __device__ __forceinline__ float gru_blend(float Z, float h, float ht) { return fmaf(Z, h, __fmul_rn(1.0f - Z, ht)); }
+// The element-wise steps of the cell's backward pass, likewise with one fixed instruction sequence each (cell_bwd8_kernel and the
+// data-gradient epilogues of the three-launch path, the fused backward kernel in fused.hip):  with g = p_t dOH[node]
+//   dhp = g (1 - Z) (1 - H~^2)        dzp = g (h - H~) Z (1 - Z)        drp = dq h R (1 - R)        dh = dq R + g Z
+//   ds = (dh + dzp Uz + drp Ur) act'(h)
+__device__ __forceinline__ float cb_dhp(float g, float z, float ht) { return __fmul_rn(__fmul_rn(g, 1.0f - z), fmaf(-ht, ht, 1.0f)); }
+__device__ __forceinline__ float cb_dzp(float g, float h, float ht, float z) { return __fmul_rn(__fmul_rn(g, h - ht), __fmul_rn(z, 1.0f - z)); }
+__device__ __forceinline__ float cb_drp(float dq, float h, float r) { return __fmul_rn(__fmul_rn(dq, h), __fmul_rn(r, 1.0f - r)); }
+__device__ __forceinline__ float cb_dh(float dq, float r, float p, float d, float z) { return fmaf(dq, r, __fmul_rn(__fmul_rn(p, d), z)); }
+__device__ __forceinline__ float cb_ds(float dh, float acc, float factor) { return __fmul_rn(dh + acc, factor); }
 
 // per tile row: byte offset of the row's node in an (N, C) fp32 array and its period's attention probability (EpiDgrad1F)
 struct EpiRowEnt { int off; float p; };
@@ -237,6 +246,20 @@ struct FusedFwdArgs {
 long fused_trace_fetch(long* out, long capacity);
 int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st);
 bool fused_forward_ok(int C, int F);
+
+// ---- fused data gradients of the cell for the bf16 arithmetic (fused.hip): cell_bwd + dgrad_candidate + dgrad_gates in one kernel
+struct FusedBwdArgs {
+    const void *ZR, *h, *Ht;                  // bf16, stored by the forward: (M x 2C) = [Z | R], (M x C), (M x C)
+    const float *dOH, *probs;                 // (nodes x C) fp32 gradient of the attention-weighted hidden state, softmax(attention) (T)
+    const void *UhTf, *UzTf, *UrTf;           // TRANSPOSED h-halves of linear_h / _z / _r (C x C) in MFMA fragment order
+    void *dhp, *dzr, *dh;                     // bf16 outputs: (M x C), (M x 2C) = [dzp | drp], (M x C) = ds
+    float* rowdot;                            // (M) fp32: <dOH[node], H'[m]> per row (attention-probability gradient, summed later)
+    long M; int T; float slope; int act_lrelu;
+};
+int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st);
+bool fused_backward_ok(int C);
+// dp_partial[b][t] = sum over the nodes of block b (nodes_per_block consecutive nodes, ascending) of rowdot[node * T + t]
+int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st);
 
 // ---- cell backward head / small element-wise kernels -------------------------------------------
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)

@@ -84,8 +84,10 @@ def test_entry_points_reject_bad_arguments_before_touching_the_gpu():
     assert rc != 0                                                 # params incomplete / grads NULL
     rc = lib.regt_spmm_csr(one, one, one, one, one, 8, 8, 6, None)
     assert rc != 0 and b"multiple of 4" in lib.regt_last_error()
-    rc = lib.regt_spmm_dual(one, one, one, one, one, one, one, 8, 48, None)
-    assert rc != 0 and b"multiple of 32" in lib.regt_last_error()
+    rc = lib.regt_spmm_dual(one, one, one, one, one, one, one, 8, 46, None)
+    assert rc != 0 and b"multiple of 4 floats" in lib.regt_last_error()
+    rc = lib.regt_spmm_dual(one, one, one, one, one, one, one, 8, 2052, None)
+    assert rc != 0 and b"neither a multiple of 32 floats nor at most 2048" in lib.regt_last_error()
     rc = lib.regt_linear(one, 8, 4, 8, one, 8, 4, None, 7, 0.0, one, 4, None)
     assert rc != 0 and b"act must be" in lib.regt_last_error()
     rc = lib.regt_wgrad(one, 4, one, 8, 16, 4, 8, one, 8, None, None, None)

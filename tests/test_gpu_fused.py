@@ -25,6 +25,7 @@ def bf16_mode():
     yield R
     lib.regt_set_gemm_mode(prev)
     lib.regt_set_option(b"xbf", 1)
+    lib.regt_set_option(b"fused_bwd", 1)
     lib.regt_set_option(b"spmm_rows", 0)
 
 
@@ -84,9 +85,10 @@ def test_row_block_kernel_equals_panel_kernel_bit_for_bit(n, e, regions, w):
     assert torch.equal(a1, a0) and torch.equal(l1, l0)
 
 
-def _run(R, n, e, regions, f, t, o, xbf, seed=0):
+def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1):
     lib = R.load_library()
     lib.regt_set_option(b"xbf", xbf)
+    lib.regt_set_option(b"fused_bwd", fused_bwd)
     ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n + seed)
     x = bf16_round(x)
     y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
@@ -116,6 +118,25 @@ def test_fused_forward_equals_three_launch_path_bit_for_bit(bf16_mode, n, e, reg
     bad = {k: v for k, v in worst.items() if v != 0.0}
     assert not bad, bad
     assert float(h1.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+# the fused backward kernel does not depend on F: the cfg-3 width (F = 32, three-launch forward) is covered as well
+@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES + [(1500, 15000, 8, 32, 12, 1), (333, 2500, 2, 32, 7, 2)])
+def test_fused_backward_equals_three_launch_backward_bit_for_bit(bf16_mode, n, e, regions, f, t, o):
+    """cell_bwd + dgrad_candidate + dgrad_gates as one kernel (csrc/fused.hip, fused_bwd_kernel): same operands, same k order, same
+    rounding points -> every gradient identical, except the attention gradient, whose per-row dots are summed in another
+    (fixed) order."""
+    R = bf16_mode
+    p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1, fused_bwd=1)
+    p0, h0, g0 = _run(R, n, e, regions, f, t, o, 1, fused_bwd=0)
+    assert torch.equal(p1, p0) and torch.equal(h1, h0)
+    assert set(g1) == set(g0)
+    worst = {k: float((g1[k] - g0[k]).abs().max()) for k in g0 if k != "tgnn._attention"}
+    bad = {k: v for k, v in worst.items() if v != 0.0}
+    assert not bad, bad
+    a1, a0 = g1["tgnn._attention"], g0["tgnn._attention"]
+    assert float((a1 - a0).abs().max()) <= 1e-4 * float(a0.abs().max()) + 1e-7, (a1, a0)
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
 def test_packed_bf16_rows_equal_packed_fp32_rows(bf16_mode):
