@@ -404,6 +404,22 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #undef FT_MARK
 }
 
+static long* g_fused_trace = nullptr;
+static long g_fused_trace_n = 0;
+// REGT_FUSED_TRACE = 1: stamps of the forward kernel, 2: of the backward kernel (8 per tile); nullptr when tracing is off
+static long* fused_trace_buffer(int which, long tiles) {
+    static int tr = -1;
+    if (tr < 0) { const char* e = getenv("REGT_FUSED_TRACE"); tr = e ? atoi(e) : 0; }
+    if (tr != which) return nullptr;
+    if (!g_fused_trace || g_fused_trace_n < 8 * tiles) {
+        if (g_fused_trace) (void)hipFree(g_fused_trace);
+        g_fused_trace = nullptr;
+        if (hipMalloc(&g_fused_trace, 8 * tiles * sizeof(long)) != hipSuccess) return nullptr;
+        g_fused_trace_n = 8 * tiles;
+    }
+    return g_fused_trace;
+}
+
 // ---- fused data gradients of the cell ---------------------------------------------------------------------------------------------
 // cell_bwd + dgrad_candidate + dgrad_gates of the three-launch backward in one kernel per 64-row tile.  With g = p_t dOH[node]:
 //     dhp = g (1 - Z) (1 - H~^2),   dzp = g (h - H~) Z (1 - Z)                       (gate pre-activation gradients: cell.hip)
@@ -441,6 +457,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;
     const unsigned node0 = mrow0 / uT;
     const long nodes = a.M / a.T;
+#define FB_MARK(i) do { if (a.trace && tid == 0) a.trace[8L * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+    FB_MARK(0);
     // the tile's rows of every activation array; dOH from the tile's first node on (rows past the end read zeros, stores are dropped)
     const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<const char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
     const __amdgpu_buffer_rsrc_t sH = f_rsrc(reinterpret_cast<const char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2);
@@ -500,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         }
         const char* pa0 = P + sp_off(lr, lh);
         const char* pa1 = P + sp_off(32 + lr, lh);
-        constexpr int AHEAD = 3;
+        constexpr int AHEAD = 2;
         bf16x8 fa[KBC + AHEAD][2];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -526,38 +544,61 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
 
     // ---- phase A: gate pre-activation gradients (element-wise): dhp -> global + planes P, dzp -> global ----------------------------
     float rdot[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int j = 0; j < NT; ++j) {
-        u32x4_t zr_[4], hr_[4], tr_[4];
+    {
+        // every operand is requested before anything is stored (a load issued behind a store waits for that store): Z, h, H~ of both
+        // column tiles up front, dOH of the second tile once the first tile's values are in registers, the stores after that
+        u32x4_t zr_[NT][4], hr_[NT][4], tr_[NT][4], o_p[4], o_z[4];
         V8 dd_[4];
+        auto ld_zht = [&](int j) {
 #pragma unroll
-        for (int rnd = 0; rnd < 4; ++rnd) {
-            const int row = 16 * rnd + er, c = 128 * j + ec;
-            zr_[rnd] = ld16(sZR, (row * 2 * C + c) * 2);
-            hr_[rnd] = ld16(sH, (row * C + c) * 2);
-            tr_[rnd] = ld16(sHt, (row * C + c) * 2);
-            dd_[rnd] = ldd8(dof_[rnd] + c * 4);
-        }
-#pragma unroll
-        for (int rnd = 0; rnd < 4; ++rnd) {
-            const int row = 16 * rnd + er, c = 128 * j + ec;
-            const V8 z = f_widen8(zr_[rnd]), h = f_widen8(hr_[rnd]), ht = f_widen8(tr_[rnd]);
-            V8 dhp, dzp;
-            float dot = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float g = __fmul_rn(pt_[rnd], dd_[rnd].v[i]);
-                dhp.v[i] = cb_dhp(g, z.v[i], ht.v[i]);
-                dzp.v[i] = cb_dzp(g, h.v[i], ht.v[i], z.v[i]);
-                dot += dd_[rnd].v[i] * (z.v[i] * h.v[i] + (1.0f - z.v[i]) * ht.v[i]);
+            for (int rnd = 0; rnd < 4; ++rnd) {
+                const int row = 16 * rnd + er, c = 128 * j + ec;
+                zr_[j][rnd] = ld16(sZR, (row * 2 * C + c) * 2);
+                hr_[j][rnd] = ld16(sH, (row * C + c) * 2);
+                tr_[j][rnd] = ld16(sHt, (row * C + c) * 2);
             }
-            rdot[rnd] += dot;
-            const u32x4_t pk = f_pack8(dhp);
-            __builtin_amdgcn_raw_buffer_store_b128(pk, sdhp, (row * C + c) * 2, 0, 0);
-            *reinterpret_cast<u32x4_t*>(Pp + plane_off(row, c)) = pk;
-            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(dzp), sdzr, (row * 2 * C + c) * 2, 0, 0);
+        };
+        auto ld_d = [&](int j) {
+#pragma unroll
+            for (int rnd = 0; rnd < 4; ++rnd) dd_[rnd] = ldd8(dof_[rnd] + (128 * j + ec) * 4);
+        };
+        ld_zht(0);
+        ld_d(0);
+        ld_zht(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int rnd = 0; rnd < 4; ++rnd) {
+                const V8 z = f_widen8(zr_[j][rnd]), h = f_widen8(hr_[j][rnd]), ht = f_widen8(tr_[j][rnd]);
+                V8 dhp, dzp;
+                float dot = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float g = __fmul_rn(pt_[rnd], dd_[rnd].v[i]);
+                    dhp.v[i] = cb_dhp(g, z.v[i], ht.v[i]);
+                    dzp.v[i] = cb_dzp(g, h.v[i], ht.v[i], z.v[i]);
+                    dot += dd_[rnd].v[i] * (z.v[i] * h.v[i] + (1.0f - z.v[i]) * ht.v[i]);
+                }
+                rdot[rnd] += dot;
+                asm volatile("" : "+v"(rdot[rnd]));              // the sum is formed here, not at its first use (keeps 1 - Z, h, H~ short-lived)
+                o_p[rnd] = f_pack8(dhp);
+                o_z[rnd] = f_pack8(dzp);
+                *reinterpret_cast<u32x4_t*>(Pp + plane_off(16 * rnd + er, 128 * j + ec)) = o_p[rnd];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (j + 1 < NT) ld_d(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int rnd = 0; rnd < 4; ++rnd) {
+                const int row = 16 * rnd + er, c = 128 * j + ec;
+                __builtin_amdgcn_raw_buffer_store_b128(o_p[rnd], sdhp, (row * C + c) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o_z[rnd], sdzr, (row * 2 * C + c) * 2, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    FB_MARK(1);
     issue_b(a.UhTf, w, 0, KBC);                                  // dq, column tile 0
 #pragma unroll
     for (int rnd = 0; rnd < 4; ++rnd) {                          // the wave's 32 columns x 2 tiles of row 16 rnd + er
@@ -573,17 +614,18 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     //      which is exactly the rounding point of the three-launch path) ----------------------------------------------------------------
     static_assert(NT == 2, "h-sign masks of two column tiles");
     unsigned hpos0 = 0, hpos1 = 0;                               // bit 8 rnd + i: h > 0 (the leaky-relu derivative of phase D)
+    u32x4_t dhk[NT][4] = {};                                     // dh, rounded to bf16 where the three-launch path stores it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < NT; ++j) {                               // (rolled: unrolled, the scheduler's hoisting costs ~1 KB of spills)
         unsigned hp = 0;
         u32x4_t xh[2], xz[2], xr[2];                             // operands of the epilogue rounds, requested one round ahead
         V8 xd[2];
         auto aux = [&](int rnd) {
             const int row = 16 * rnd + er, c = 128 * j + ec;
+            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);  // R: first touch (HBM); h, Z, dOH were read in phase A
             xh[rnd & 1] = ld16(sH, (row * C + c) * 2);
             xz[rnd & 1] = ld16(sZR, (row * 2 * C + c) * 2);
-            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);
             xd[rnd & 1] = ldd8(dof_[rnd] + c * 4);
         };
         aux(0);
@@ -606,12 +648,18 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
                 hp |= (h.v[i] > 0.f ? 1u : 0u) << (8 * rnd + i);
             }
             const u32x4_t pr = f_pack8(drp);
-            __builtin_amdgcn_raw_buffer_store_b128(pr, sdzr, (row * 2 * C + C + c) * 2, 0, 0);
             *reinterpret_cast<u32x4_t*>(Rp + plane_off(row, c)) = pr;
-            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(dh), sdh, (row * C + c) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pr, sdzr, (row * 2 * C + C + c) * 2, 0, 0);
+            {
+                const u32x4_t pk = f_pack8(dh);
+                if (j == 0) dhk[0][rnd] = pk;
+                else dhk[1][rnd] = pk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (j == 0) hpos0 = hp;
         else hpos1 = hp;
+        FB_MARK(2 + j);
     }
     __syncthreads();                                            // planes R (drp) complete, every wave is done with dhp in planes P
 
@@ -619,9 +667,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     //      stores of phase A) while the first product runs, and takes dhp's place in planes P --------------------------------------------
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        u32x4_t dhr[4], dzk[NT][4];
-#pragma unroll
-        for (int rnd = 0; rnd < 4; ++rnd) dhr[rnd] = ld16(sdh, ((16 * rnd + er) * C + 128 * j + ec) * 2);
+        u32x4_t dzk[NT][4];
         if (j == 0) {
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj)
@@ -630,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         }
         f32x16 acc[2];
         kloop(acc, Rp, true, a.UzTf, 4 * j + w);
+        if (j == 0) FB_MARK(4);
         if (j == 0) {
 #pragma unroll
             for (int jj = 0; jj < NT; ++jj)
@@ -643,7 +690,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
             const V8 v = img8();
-            const V8 d = f_widen8(dhr[rnd]);
+            const V8 d = f_widen8(dhk[j][rnd]);
             V8 o;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -652,10 +699,14 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
             }
             __builtin_amdgcn_raw_buffer_store_b128(f_pack8(o), sdh, ((16 * rnd + er) * C + 128 * j + ec) * 2, 0, 0);
         }
+        FB_MARK(5 + j);
     }
+#undef FB_MARK
 }
 
-int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st) {
+int launch_fused_backward(const FusedBwdArgs& a_, int C, hipStream_t st) {
+    FusedBwdArgs a = a_;
+    a.trace = fused_trace_buffer(2, (a_.M + FT_ROWS - 1) / FT_ROWS);
     REGT_CHECK_ARG(a.M > 0 && a.T > 0 && a.M % a.T == 0, "fused backward: empty problem");
     REGT_CHECK_ARG(C == 256, "fused backward: built for C = 256 (got C = %d)", C);
     const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
@@ -672,8 +723,6 @@ int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st) {
 }
 bool fused_backward_ok(int C) { return C == 256; }
 
-static long* g_fused_trace = nullptr;
-static long g_fused_trace_n = 0;
 // copies the stamps of the last traced launch to the host (synchronises); returns the number of values
 long fused_trace_fetch(long* out, long capacity) {
     if (!g_fused_trace || !out) return 0;
@@ -688,20 +737,7 @@ int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
     if (dbg < 0) { const char* e = getenv("REGT_FUSED_DBG"); dbg = e ? atoi(e) : 0; }
     FusedFwdArgs a = a_;
     a.dbg = dbg;
-    a.trace = nullptr;
-    {
-        static int tr = -1;
-        if (tr < 0) { const char* e = getenv("REGT_FUSED_TRACE"); tr = e ? atoi(e) : 0; }
-        if (tr) {
-            const long tiles_t = (a_.M + FT_ROWS - 1) / FT_ROWS;
-            if (!g_fused_trace || g_fused_trace_n < 8 * tiles_t) {
-                if (g_fused_trace) (void)hipFree(g_fused_trace);
-                REGT_CHECK_HIP(hipMalloc(&g_fused_trace, 8 * tiles_t * sizeof(long)));
-                g_fused_trace_n = 8 * tiles_t;
-            }
-            a.trace = g_fused_trace;
-        }
-    }
+    a.trace = fused_trace_buffer(1, (a_.M + FT_ROWS - 1) / FT_ROWS);
     REGT_CHECK_ARG(C == 256 && F == 64, "fused forward: built for C = 256, F = 64 (got C = %d, F = %d)", C, F);
     const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
     REGT_CHECK_ARG(tiles < (1L << 31), "fused forward: too many tiles");

@@ -255,6 +255,7 @@ struct FusedBwdArgs {
     void *dhp, *dzr, *dh;                     // bf16 outputs: (M x C), (M x 2C) = [dzp | drp], (M x C) = ds
     float* rowdot;                            // (M) fp32: <dOH[node], H'[m]> per row (attention-probability gradient, summed later)
     long M; int T; float slope; int act_lrelu;
+    long* trace;                              // developer trace buffer (REGT_FUSED_TRACE=2) or nullptr
 };
 int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st);
 bool fused_backward_ok(int C);
