@@ -773,8 +773,8 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             S.seg[1] = make_seg(L.dzr, 2L * C, wb.UT[1], nullptr, C, INT_MAX, C, true, SEG_A_BF16 | SEG_B_FRAG);
         } else if (split) {
             const int fl = ibf ? SEG_A_BF16 : 0;
-            S.seg[0] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true, fl);
-            S.seg[1] = make_seg(byte_off(L.dzr, (ibf ? 2L : 4L) * C), 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true, fl);
+            S.seg[0] = make_seg(byte_off(L.dzr, (ibf ? 2L : 4L) * C), 2L * C, L.UT + 2L * C * C, nullptr, C, INT_MAX, C, true, fl);
+            S.seg[1] = make_seg(L.dzr, 2L * C, L.UT + (long)C * C, nullptr, C, INT_MAX, C, true, fl);
         } else {
             S.seg[0] = make_seg(L.dzr, 2L * C, p.gate_w[0] + C, nullptr, 2L * C, INT_MAX, C, false);
             S.seg[1] = make_seg(L.dzr + C, 2L * C, p.gate_w[1] + C, nullptr, 2L * C, INT_MAX, C, false);

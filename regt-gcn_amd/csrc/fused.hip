@@ -125,6 +125,13 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             xf[0][kb] = f_ldfrag(sX, afo, kb * 32);
             xf[1][kb] = f_ldfrag(sX, afo + 32 * F * 2, kb * 32);
         }
+        // (L~ x rows too, unmasked: waiting for the region lookup first would put two memory latencies in series; rows of
+        // another region than the tile's first are zeroed in registers below)
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) {
+            lf[0][kb] = f_ldfrag(sLX, afo, kb * 32);
+            lf[1][kb] = f_ldfrag(sLX, afo + 32 * F * 2, kb * 32);
+        }
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) b0[0][kb] = f_ldfrag(sA0, lane * 16, (w * KBF + kb) * 1024);
     }
@@ -142,15 +149,17 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         ptr_[rnd] = a.probs[m - (m / uT) * uT];
     }
     {
-        const int o0 = rg_a == rg0 ? afo : 0x7ffffff0, o1 = rg_b == rg0 ? afo + 32 * F * 2 : 0x7ffffff0;
         const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
 #pragma unroll
-        for (int kb = 0; kb < KBF; ++kb) {
-            lf[0][kb] = f_ldfrag(sLX, o0, kb * 32);
-            lf[1][kb] = f_ldfrag(sLX, o1, kb * 32);
-        }
-#pragma unroll
         for (int kb = 0; kb < KBF; ++kb) b0[1][kb] = f_ldfrag(sAr, lane * 16, (w * KBF + kb) * 1024);
+        if (multi) {                                             // rare: rows of the tile's other regions contribute to THEIR region's pass
+            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int kb = 0; kb < KBF; ++kb) {
+                lf[0][kb] = rg_a == rg0 ? lf[0][kb] : zero;
+                lf[1][kb] = rg_b == rg0 ? lf[1][kb] : zero;
+            }
+        }
     }
     FT_MARK(1);
 

@@ -31,4 +31,7 @@ def _ab(spec_b, mode, nodes, feat):
 ])
 def test_switch_reproduces_default(switch, mode, rel):
     for name, diff, scale in _ab(switch, mode, 3000, 32):
-        assert diff <= rel * scale + (0.0 if rel == 0.0 else 1e-9), (switch, mode, name, diff, scale)
+        # bf16 without fragment-order weights also leaves the fused backward kernel (csrc/fused.hip), which sums the
+        # attention-probability gradient's per-row dots in another fixed order: that one tensor is held to 1e-5
+        r = 1e-5 if (mode == 2 and name == "g:tgnn._attention") else rel
+        assert diff <= r * scale + (0.0 if r == 0.0 else 1e-9), (switch, mode, name, diff, scale)
