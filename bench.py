@@ -404,7 +404,7 @@ def main():
     pipe = None
     # bf16 arithmetic at the shape the fused forward covers: x, A_hat x, L~ x are bf16 rows (a region shard packs and exchanges
     # its rows as bf16)
-    rows_bf16 = mode == 2 and F == 64 and regions > 1 and os.environ.get("REGT_XBF", "1") != "0"
+    rows_bf16 = mode == 2 and F in (32, 64) and (T * F) % 64 == 0 and regions > 1 and os.environ.get("REGT_XBF", "1") != "0"
     if world == 1 and not force_shard and not shard_of_8:
         graph = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index],
                                 [t.to(dev) for t in g.region_attr], n_local)

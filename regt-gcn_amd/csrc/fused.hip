@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
     const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
     // (timing-only switches, REGT_FUSED_DBG: bit 0 = zero-record store descriptors: every activation store is dropped by the range
-    // check; bit 1 = zero-record weight descriptors: fragment loads return 0 without traffic -- cdna_hip_programming.md section 7)
+    // check; bit 1 = zero-record weight descriptors: fragment loads return 0 without traffic -- cdna_hip_programming.md section 7;
+    // bit 2 = no per-node column sums at all, bit 3 = column sums without their atomic adds)
     const int st_on = (a.dbg & 1) ? 0 : 1, w_on = (a.dbg & 2) ? 0 : 1;
     const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
     const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             float4* p = reinterpret_cast<float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
             p[0] = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
             p[1] = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
-            if (lh == 0) {
+            if (lh == 0 && !(a.dbg & 4)) {
 #pragma unroll
                 for (int r8 = 0; r8 < FT_IMG_ROWS; r8 += 8) {          // LDS reads of 8 rows first, then the serial chain on registers
                     float cv[8];
@@ -396,7 +397,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
                         const int row = 16 * rnd + r8 + r;             // (all of this control flow is wave-uniform)
                         if (row < nvalid) {
                             if (tc == 0 && row > 0) {                  // the row starts a new node: hand the finished one over
-                                atomicAdd(oh + (long)nd * C, csum);
+                                // (a node that began in this tile has no rows elsewhere: a plain store into the zeroed array;
+                                // only the tile's first node can continue a node of the previous tile)
+                                if (a.dbg & 8) {}
+                                else if (nd > 0 || t0 == 0) oh[(long)nd * C] = csum;
+                                else atomicAdd(oh, csum);
                                 ++nd;
                                 csum = 0.f;
                             }
@@ -407,7 +412,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
                 }
             }
         }
-        if (lh == 0) atomicAdd(oh + (long)nd * C, csum);
+        if (lh == 0 && !(a.dbg & 12)) {          // the last node: complete iff it began here and its last period is the tile's last row
+            if (tc == 0 && (nd > 0 || t0 == 0)) oh[(long)nd * C] = csum;
+            else atomicAdd(oh + (long)nd * C, csum);
+        }
         FT_MARK(5 + 2 * j);
     }
 #undef FT_MARK
@@ -747,19 +755,21 @@ int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
     FusedFwdArgs a = a_;
     a.dbg = dbg;
     a.trace = fused_trace_buffer(1, (a_.M + FT_ROWS - 1) / FT_ROWS);
-    REGT_CHECK_ARG(C == 256 && F == 64, "fused forward: built for C = 256, F = 64 (got C = %d, F = %d)", C, F);
+    REGT_CHECK_ARG(fused_forward_ok(C, F), "fused forward: built for C = 256, F = 32 or 64 (got C = %d, F = %d)", C, F);
     const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
     REGT_CHECK_ARG(tiles < (1L << 31), "fused forward: too many tiles");
-    using L = FusedFwdLds<256, 64>;
+    using L = FusedFwdLds<256, 64>;              // (the LDS footprint does not depend on F)
     static bool attr_done = false;
     if (!attr_done) {
         REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<256, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    if (F == 64) hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    else hipLaunchKernelGGL((fused_fwd_kernel<256, 32>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
-bool fused_forward_ok(int C, int F) { return C == 256 && F == 64; }
+bool fused_forward_ok(int C, int F) { return C == 256 && (F == 64 || F == 32); }
 
 }  // namespace regt

@@ -2305,7 +2305,9 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
     // (any width when both parts are stored as bf16: the fused [q | A_hat x] / [h | A_hat x] gradients of the bf16-row layout)
     const bool q2_split = a.Q2 && gemm_mode() == 2 && a.Nin > 32 && (a.Nin <= 128 || a.q_bf16) && !a.q_relu && a.nin_split % (a.q_bf16 ? 8 : 4) == 0 &&
                           !fp32_core_wide() && (!a.q_bf16 || a.ldq2 % 8 == 0);
-    const bool wide = a.Nin > 32 && (!a.Q2 || q2_split);
+    // (a bf16-stored right-hand side of width <= 32 -- A_hat x rows at F = 32 -- also takes the bf16-pipe kernel: the skinny one
+    // stages fp32 rows only; the stage is HBM-bound on its left operand either way)
+    const bool wide = (a.Nin > 32 || (a.q_bf16 && gemm_mode() == 2 && !a.Q2)) && (!a.Q2 || q2_split);
     const int bnw = wide ? 128 : 32;
     long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
     REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");

@@ -105,7 +105,7 @@ def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1):
 # (nodes, edges, regions, F, T, O): 64 regions = configs[4]; O = 3; T = 5 and a row count that is no multiple of 64 (tail tile,
 # tiles that start inside a node); T = 48 (a node spans two 64-row tiles); one region per ~100 nodes (tiles with two regions)
 FUSED_SHAPES = [(2048, 20000, 64, 64, 12, 1), (1200, 9000, 4, 64, 12, 3), (701, 5000, 3, 64, 5, 1), (400, 3000, 2, 64, 48, 1),
-                (600, 4000, 6, 64, 1, 1)]
+                (600, 4000, 6, 64, 1, 1), (1500, 15000, 8, 32, 12, 1), (450, 3000, 3, 32, 6, 2)]       # F = 32: the cfg-3 width
 
 
 @pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES)
@@ -114,14 +114,21 @@ def test_fused_forward_equals_three_launch_path_bit_for_bit(bf16_mode, n, e, reg
     p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1)
     p0, h0, g0 = _run(R, n, e, regions, f, t, o, 0)
     worst = {"pred": float((p1 - p0).abs().max()), "hidden": float((h1 - h0).abs().max())}
-    worst.update({k: float((g1[k] - g0[k]).abs().max()) for k in g0})
-    bad = {k: v for k, v in worst.items() if v != 0.0}
-    assert not bad, bad
+    assert worst["pred"] == 0.0 and worst["hidden"] == 0.0, worst
+    if f == 32:
+        # F = 32: the (C x F) gradients dGh / dGzr run on another kernel when A_hat x is stored as bf16 rows (bf16-pipe kernel, its
+        # own row chunks) than when it is fp32 (skinny fp32-MFMA kernel): same products, another summation order
+        for k in g0:
+            assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * float(g0[k].abs().max()) + 1e-9, k
+    else:
+        worst.update({k: float((g1[k] - g0[k]).abs().max()) for k in g0})
+        bad = {k: v for k, v in worst.items() if v != 0.0}
+        assert not bad, bad
     assert float(h1.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
-# the fused backward kernel does not depend on F: the cfg-3 width (F = 32, three-launch forward) is covered as well
-@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES + [(1500, 15000, 8, 32, 12, 1), (333, 2500, 2, 32, 7, 2)])
+# the fused backward kernel does not depend on F, nor on the forward being the fused one ((333, ..., 32, 7): T F % 64 != 0)
+@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES + [(333, 2500, 2, 32, 7, 2)])
 def test_fused_backward_equals_three_launch_backward_bit_for_bit(bf16_mode, n, e, regions, f, t, o):
     """cell_bwd + dgrad_candidate + dgrad_gates as one kernel (csrc/fused.hip, fused_bwd_kernel): same operands, same k order, same
     rounding points -> every gradient identical, except the attention gradient, whose per-row dots are summed in another

@@ -26,12 +26,14 @@ def _ab(spec_b, mode, nodes, feat):
 
 @pytest.mark.parametrize("switch,mode,rel", [
     ("REGT_GEMM_DESC=table", 0, 0.0),        # same kernels, descriptors from the LDS table: bit-identical
-    ("REGT_GEMM_DESC=table", 2, 0.0),        # bf16: also turns the fragment-order weights off -- same rounding, same sums
+    # bf16: also turns the fragment-order weights off, and with them the bf16 rows of x / A_hat x / L~ x and the fused kernels
+    # (x is then aggregated unrounded and rounded at LDS staging instead of once while it is packed): same arithmetic, one
+    # rounding point moved -- held to the bf16 bar of tests/test_gpu_bf16.py (8 u)
+    ("REGT_GEMM_DESC=table", 2, 8 * 2.0 ** -9),
     ("REGT_FP32_CORE=wide", 0, 1e-5),        # two-workgroup kernels: a node's two partial sums are added in another order
 ])
 def test_switch_reproduces_default(switch, mode, rel):
     for name, diff, scale in _ab(switch, mode, 3000, 32):
-        # bf16 without fragment-order weights also leaves the fused backward kernel (csrc/fused.hip), which sums the
-        # attention-probability gradient's per-row dots in another fixed order: that one tensor is held to 1e-5
-        r = 1e-5 if (mode == 2 and name == "g:tgnn._attention") else rel
+        # (the attention gradient is a difference of nearly equal terms: 6 x the bar, as in tests/test_gpu_bf16.py)
+        r = 6 * rel if (mode == 2 and name == "g:tgnn._attention") else rel
         assert diff <= r * scale + (0.0 if r == 0.0 else 1e-9), (switch, mode, name, diff, scale)
