@@ -1133,6 +1133,9 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
         const int cc = n0 + 4 * c4;
         if (cc >= a.C) continue;
         long lo = (long)node * a.T - m0, hi = lo + a.T - 1;
+        // all T rows of the node inside this tile: nobody else adds to its row of the zero-initialised hidden state -- one
+        // 16-byte store instead of four atomics (which remain for the tile's first / last, partial nodes)
+        const bool whole = lo >= 0 && hi <= rm.nvalid - 1;
         if (lo < 0) lo = 0;
         if (hi > rm.nvalid - 1) hi = rm.nvalid - 1;
         float4 s4 = make_float4(0, 0, 0, 0);
@@ -1141,7 +1144,8 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat_kernel(CandArgs a) {
             s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         }
         float* o = a.OH + (long)node * C + cc;
-        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+        if (whole) *reinterpret_cast<float4*>(o) = s4;
+        else { atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w); }
     }
 }
 
@@ -1222,6 +1226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat8_kernel(CandArgs a) {
         const int cc = n0 + 4 * c4;
         if (cc >= a.C) continue;
         long lo = (long)node * a.T - m0, hi = lo + a.T - 1;
+        // all T rows of the node inside this tile: nobody else adds to its row of the zero-initialised hidden state -- one
+        // 16-byte store instead of four atomics (which remain for the tile's first / last, partial nodes)
+        const bool whole = lo >= 0 && hi <= rm.nvalid - 1;
         if (lo < 0) lo = 0;
         if (hi > rm.nvalid - 1) hi = rm.nvalid - 1;
         float4 s4 = make_float4(0, 0, 0, 0);
@@ -1230,7 +1237,8 @@ __global__ __launch_bounds__(256, 2) void gemm_cand_flat8_kernel(CandArgs a) {
             s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
         }
         float* o = a.OH + (long)node * C + cc;
-        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+        if (whole) *reinterpret_cast<float4*>(o) = s4;
+        else { atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w); }
     }
 }
 
@@ -1294,6 +1302,7 @@ __device__ __forceinline__ void cand_epilogue(const CandArgs& a, const SplitCore
                 const int n_first = rowtab[r_lo].nt >> 8, n_last = rowtab[r_hi].nt >> 8;
                 for (int nd = n_first + rr; nd <= n_last; nd += 8) {
                     int lo = nd * a.T - t0, hi = lo + a.T - 1;               // the node's rows in tile coordinates
+                    const bool whole = lo >= r_lo && hi <= r_hi;             // all of the node's rows in this half: plain store
                     lo = lo < r_lo ? r_lo : lo;
                     hi = hi > r_hi ? r_hi : hi;
                     float4 s4 = make_float4(0, 0, 0, 0);
@@ -1303,7 +1312,8 @@ __device__ __forceinline__ void cand_epilogue(const CandArgs& a, const SplitCore
                     }
                     if (col_ok) {
                         float* o = a.OH + (long)(node0 + nd) * C + n0 + c4;
-                        atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w);
+                        if (whole) *reinterpret_cast<float4*>(o) = s4;
+                        else { atomicAdd(o + 0, s4.x); atomicAdd(o + 1, s4.y); atomicAdd(o + 2, s4.z); atomicAdd(o + 3, s4.w); }
                     }
                 }
             }
@@ -1401,6 +1411,7 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
                 const int n_first = rowtab[r_lo].nt >> 8, n_last = rowtab[r_hi].nt >> 8;
                 for (int nd = n_first + rr; nd <= n_last; nd += 16) {
                     int lo = nd * a.T - t0, hi = lo + a.T - 1;
+                    const bool whole = lo >= r_lo && hi <= r_hi;
                     lo = lo < r_lo ? r_lo : lo;
                     hi = hi > r_hi ? r_hi : hi;
                     float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
@@ -1412,8 +1423,13 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
                     }
                     if (col_ok) {
                         float* o = a.OH + (long)(node0 + nd) * C + n0 + c8;
-                        atomicAdd(o + 0, s0.x); atomicAdd(o + 1, s0.y); atomicAdd(o + 2, s0.z); atomicAdd(o + 3, s0.w);
-                        atomicAdd(o + 4, s1.x); atomicAdd(o + 5, s1.y); atomicAdd(o + 6, s1.z); atomicAdd(o + 7, s1.w);
+                        if (whole) {
+                            reinterpret_cast<float4*>(o)[0] = s0;
+                            reinterpret_cast<float4*>(o)[1] = s1;
+                        } else {
+                            atomicAdd(o + 0, s0.x); atomicAdd(o + 1, s0.y); atomicAdd(o + 2, s0.z); atomicAdd(o + 3, s0.w);
+                            atomicAdd(o + 4, s1.x); atomicAdd(o + 5, s1.y); atomicAdd(o + 6, s1.z); atomicAdd(o + 7, s1.w);
+                        }
                     }
                 }
             }
