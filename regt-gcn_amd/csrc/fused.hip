@@ -16,10 +16,11 @@
 // the weights in MFMA fragment order (launch_cvt_bf16_frag): a wave loads its fragments of a whole K loop up front, straight
 // into registers.  The K = F operands (x, L~ x, A_hat x: bf16 rows written by the aggregation kernel) are loaded as A
 // fragments directly from global memory (A_hat x once per tile, kept in registers for all six K loops that use it).
-// Epilogues go through a 16-row fp32 image in LDS (4 rounds per 64 x 128 tile): a thread then owns (row, 8 consecutive
-// columns) = 16 bytes of every bf16 array -- the same thread owns the same (row, columns) in the Z and in the candidate
-// epilogue, which is what lets Z stay in registers.  LDS: 32 KB h planes + 32 KB q planes + 8.4 KB image + tables = 74 KB,
-// two workgroups per CU: one's epilogue VALU and stores overlap the other's matrix work.
+// Epilogues: every wave transposes its OWN 64 x 32 accumulator strip through a wave-private 16-row fp32 image in LDS (4 rounds
+// per 64 x 128 tile, no workgroup barrier): a lane then owns (row, 8 consecutive columns) = 16 bytes of every bf16 array -- the
+// same lane owns the same (row, columns) in the Z and in the candidate epilogue, which is what lets Z stay in registers.
+// LDS: 32 KB h planes + 32 KB q planes + 4 x 2.3 KB images = 74,752 B, two workgroups per CU: one's epilogue VALU and stores
+// overlap the other's matrix work.  DESIGN.md section 5d has the measurements behind each of these choices.
 //
 // Arithmetic, rounding points and summation orders are exactly those of the three-launch path (bf16 MFMA operands, fp32
 // accumulate over k in ascending 16-k blocks, fp32 gate math, one rounding per stored element, per-node partial sums over a
@@ -32,8 +33,6 @@
 namespace regt {
 
 namespace {
-
-struct FRow { int node; float p; };      // node index relative to the tile's first node (-1: row past the end), attention probability
 
 __device__ __forceinline__ float f_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float f_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
