@@ -111,18 +111,27 @@ def topology_from_sources(sources: np.ndarray, owner_bounds: np.ndarray, rank: i
         return ShardTopology(rank, world, lo, hi, need, [empty])
     if not dist.is_initialized() or dist.get_world_size(group) != world:
         raise RuntimeError("topology_from_sources needs a process group of `world` ranks (the send lists come from the peers)")
+    send = exchange_need_lists(need, world, group)
+    send[rank] = empty
+    return ShardTopology(rank, world, lo, hi, need, send)
+
+
+def exchange_need_lists(need: List[np.ndarray], world: int, group=None) -> List[np.ndarray]:
+    """``need[s]`` = ids this rank wants from rank s  ->  ``send[r]`` = ids rank r wants from this rank: one all-gather of the
+    list lengths and one all-to-all of the concatenated id lists (int64; device tensors under 'nccl', CPU tensors under 'gloo')."""
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    rank = dist.get_rank(group)
     counts = torch.tensor([a.size for a in need], dtype=torch.int64, device=dev)
     table = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(table, counts, group=group)                        # table[r][s] = how many ids rank r needs from rank s
     send_counts = [int(table[r][rank]) for r in range(world)]
     out = torch.empty(sum(send_counts), dtype=torch.int64, device=dev)
+    empty = np.zeros(0, dtype=np.int64)
     inp = torch.from_numpy(np.concatenate(need) if sum(a.size for a in need) else empty).to(dev)
-    dist.all_to_all_single(out, inp, send_counts, [a.size for a in need], group=group)
+    dist.all_to_all_single(out, inp, send_counts, [int(a.size) for a in need], group=group)
     out = out.cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(send_counts)])
-    send = [out[offs[r]:offs[r + 1]].copy() if r != rank else empty for r in range(world)]
-    return ShardTopology(rank, world, lo, hi, need, send)
+    return [out[offs[r]:offs[r + 1]].copy() for r in range(world)]
 
 
 # Rehearsal aid (bench.py --force-shard-path): issue the collectives even in a 1-rank group, so that the exact RCCL calls

@@ -51,6 +51,15 @@ def _worker(port, q):
         assert torch.equal(p[0].grad, torch.full((5, 3), 2.0, device=dev))
         tot = R.dist.allreduce_sum(torch.tensor([1.5, 2.5], device=dev))
         assert tot.tolist() == [1.5, 2.5]
+        # graph preparation of an own-rows shard (dist.build_shard): the id-list exchange (int64 all_gather + all_to_all_single
+        # with split lists, here a rank exchanging with itself) and the all-reduce of the published D^-1/2 vector
+        back = R.dist.exchange_need_lists([np.arange(3, 20, dtype=np.int64)], 1)
+        assert len(back) == 1 and np.array_equal(back[0], np.arange(3, 20))
+        assert R.dist.exchange_need_lists([np.zeros(0, dtype=np.int64)], 1)[0].size == 0
+        dis = torch.rand(100_000, device=dev)
+        keep = dis.clone()
+        R.dist.allreduce_sum(dis)
+        assert torch.equal(dis, keep)
         dist.barrier()
         tmax = torch.tensor([3.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
