@@ -748,18 +748,21 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             PROF("fused_backward", st);
             TRY(launch_fused_backward(a, C, st));
         }
-        if (gr.attention) {
-            TRY(launch_rowdot_reduce(L.rowdot, L.dp_partial, N, T, L.cb_npb, st));
-            TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
+        if (gr.attention) {      // (one-workgroup tail of the attention gradient: off the critical path, joined before the slab reduction)
+            hipStream_t sa = side_fork(st);
+            TRY(launch_rowdot_reduce(L.rowdot, L.dp_partial, N, T, L.cb_npb, sa));
+            TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, sa));
         }
     } else {
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
         a.out_bf16 = ibf; a.in_bf16 = abf;
-        PROF("cell_bwd", st);
-        TRY(launch_cell_bwd(a, st));
-        if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, st));
+        {
+            PROF("cell_bwd", st);
+            TRY(launch_cell_bwd(a, st));
+        }
+        if (gr.attention) TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, side_fork(st)));
     }
     {   // dq = dhp Uh2 ; drp -> dzr[:, C:], dh = dq*R + p_t dOH Z
         GemmSegs S{};

@@ -2522,6 +2522,60 @@ __global__ __launch_bounds__(256) void small_gemm_multi_kernel(SgBatch B) {
     while (ti + 1 < B.ntask && (int)blockIdx.x >= B.block_start[ti + 1]) ++ti;
     // field-wise copy of the selected task (scalar selects; no dynamically indexed kernarg struct in scratch)
     const SgTask& T = B.task[ti];
+    if (T.split == 0) {
+        // Tiled form for the matrix-sized tasks (C x C, C x F outputs with K = F .. R C): one 32 x 32 output tile per workgroup,
+        // 32-k chunks of both operands staged through LDS (each element is read from memory once per tile instead of once per
+        // output element), a thread owns 2 x 2 outputs; sums run over (term, batch, k) in ascending order: deterministic.
+        // Whichever of a tile's two indices is contiguous in memory is the one consecutive lanes walk.
+        __shared__ float As[32][34], Bs[32][34];
+        const int tiles_m = (T.m + 31) / 32, tiles_n = (T.n + 31) / 32;
+        int w = blockIdx.x - B.block_start[ti];
+        const int b = w / (tiles_m * tiles_n);
+        w -= b * tiles_m * tiles_n;
+        const int i0 = (w / tiles_n) * 32, j0 = (w % tiles_n) * 32;
+        const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+        float c00 = 0.f, c01 = 0.f, c10 = 0.f, c11 = 0.f;
+        for (int t = 0; t < T.nterm; ++t) {
+            const SgTerm& q = T.term[t];
+            const int b0 = q.sum_batch ? 0 : b, b1 = q.sum_batch ? q.batch : b + 1;
+            const bool a_kfast = q.sak == 1, b_kfast = q.sbk == 1;
+            for (int bb = b0; bb < b1; ++bb) {
+                const float* A = q.A + (long)bb * q.sab;
+                const float* Bp = q.B + (long)bb * q.sbb;
+                for (int k0 = 0; k0 < q.k; k0 += 32) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int e = threadIdx.x + 256 * e4;
+                        const int ia = a_kfast ? e >> 5 : e & 31, ka = a_kfast ? e & 31 : e >> 5;
+                        As[ka][ia] = (i0 + ia < T.m && k0 + ka < q.k) ? A[(long)(i0 + ia) * q.sai + (long)(k0 + ka) * q.sak] : 0.f;
+                        const int jb = b_kfast ? e >> 5 : e & 31, kb = b_kfast ? e & 31 : e >> 5;
+                        Bs[kb][jb] = (j0 + jb < T.n && k0 + kb < q.k) ? Bp[(long)(k0 + kb) * q.sbk + (long)(j0 + jb) * q.sbj] : 0.f;
+                    }
+                    __syncthreads();
+#pragma unroll 8
+                    for (int k = 0; k < 32; ++k) {
+                        const float a0 = As[k][2 * ty], a1 = As[k][2 * ty + 1], v0 = Bs[k][2 * tx], v1 = Bs[k][2 * tx + 1];
+                        c00 = fmaf(a0, v0, c00); c01 = fmaf(a0, v1, c01);
+                        c10 = fmaf(a1, v0, c10); c11 = fmaf(a1, v1, c11);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        const float cc[2][2] = {{c00, c01}, {c10, c11}};
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int i = i0 + 2 * ty + di, j = j0 + 2 * tx + dj;
+                if (i < T.m && j < T.n) {
+                    float v = cc[di][dj];
+                    if (T.init) v += T.init[(long)i * T.init_si + (long)j * T.init_sj];
+                    T.C[(long)b * T.scb + (long)i * T.sci + (long)j * T.scj] = v;
+                }
+            }
+        return;
+    }
     const long per = (long)T.m * T.n, total = per * T.nbatch;
     const int sp = T.split;                    // uniform per workgroup: a task starts on a workgroup boundary
     const int sub = sp == 8 ? (threadIdx.x & 7) : 0;
@@ -2566,9 +2620,19 @@ int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
         REGT_CHECK_ARG(outputs > 0, "small_gemm_multi: empty task %d", t);
         long ksum = 0;                           // multiply-adds per output element
         for (int q = 0; q < task.nterm; ++q) ksum += (long)task.term[q].k * (task.term[q].sum_batch ? task.term[q].batch : 1);
-        // eight lanes per output (strided k + xor tree) only pay off for long sums; a K = F product is one lane's work
-        task.split = ksum > 32 ? 8 : 1;
-        blocks += cdiv(outputs * task.split, 256);
+        // eight lanes per output (strided k + xor tree) only pay off for long sums; a K = F product is one lane's work;
+        // matrix-sized outputs take the tiled form (split = 0)
+        // (sums longer than 256 over few tiles -- d cheb_w1 = sum over the owned regions, K = R C -- stay on the 8-lane form: 16
+        // workgroups walking 64 chunks each were slower, 0.25 vs 0.15 ms for the launch; REGT_SG_TILED_MAXK: developer switch)
+        static long tiled_maxk = -1;
+        if (tiled_maxk < 0) { const char* e = getenv("REGT_SG_TILED_MAXK"); tiled_maxk = e ? atol(e) : 256; }
+        if (task.m >= 16 && task.n >= 16 && ksum >= 16 && ksum <= tiled_maxk) {
+            task.split = 0;
+            blocks += (int)((long)cdiv(task.m, 32) * cdiv(task.n, 32) * task.nbatch);
+        } else {
+            task.split = ksum > 32 ? 8 : 1;
+            blocks += cdiv(outputs * task.split, 256);
+        }
     }
     b.block_start[b.ntask] = blocks;
     hipLaunchKernelGGL(small_gemm_multi_kernel, dim3(blocks), dim3(256), 0, st, b);
