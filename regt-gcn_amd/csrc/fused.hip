@@ -443,7 +443,8 @@ static long* fused_trace_buffer(int which, long tiles) {
 //     ds  = (dh + dzp Uz2 + drp Ur2) act'(h)                                          (back through linear_z / _r, into the embedding)
 // i.e. the transposes of models/utils.py:168-188 in the composed form of DESIGN.md section 3.  The three launches read Z (twice),
 // R, h (three times), H~, dhp, [dzp|drp] and dh back from HBM: 11 activation reads + 5 writes of M x C bf16 per step; here Z, R, h,
-// H~ are read and dhp, dzp, drp, ds written once (h, Z and dOH are read a second time in the dq epilogue, from L2 / MALL).
+// H~ are read and dhp, dzp, drp, ds written once (Z and dOH are read a second time in the dq epilogue, dzp comes back once; h waits
+// in LDS).
 // Same tile shape, fragment loads, plane layout and wave-private epilogue images as the forward kernel above: dhp is the A operand of
 // the dq product (planes P), drp fills planes R from the dq epilogues, dzp is fetched back (L2) while drp Ur2 runs and takes dhp's
 // place in P; ds accumulates drp Ur2 + dzp Uz2 in one K = 2C loop (the order of the three-launch kernel), dh makes the same round
@@ -601,6 +602,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
                 o_p[rnd] = f_pack8(dhp);
                 o_z[rnd] = f_pack8(dzp);
                 *reinterpret_cast<u32x4_t*>(Pp + plane_off(16 * rnd + er, 128 * j + ec)) = o_p[rnd];
+                // h waits for the dq epilogue in the (still empty) planes R, at the very place the same lane will put drp
+                *reinterpret_cast<u32x4_t*>(Rp + plane_off(16 * rnd + er, 128 * j + ec)) = hr_[j][rnd];
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (j + 1 < NT) ld_d(j + 1);
@@ -635,12 +638,11 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {                               // (rolled: unrolled, the scheduler's hoisting costs ~1 KB of spills)
         unsigned hp = 0;
-        u32x4_t xh[2], xz[2], xr[2];                             // operands of the epilogue rounds, requested one round ahead
+        u32x4_t xz[2], xr[2];                                    // operands of the epilogue rounds, requested one round ahead
         V8 xd[2];
         auto aux = [&](int rnd) {
             const int row = 16 * rnd + er, c = 128 * j + ec;
-            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);  // R: first touch (HBM); h, Z, dOH were read in phase A
-            xh[rnd & 1] = ld16(sH, (row * C + c) * 2);
+            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);  // R: first touch (HBM); Z, dOH were read in phase A; h is in planes R
             xz[rnd & 1] = ld16(sZR, (row * 2 * C + c) * 2);
             xd[rnd & 1] = ldd8(dof_[rnd] + c * 4);
         };
@@ -655,7 +657,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
             stage(acc, rnd);
             const V8 v = img8();
             const int row = 16 * rnd + er, c = 128 * j + ec;
-            const V8 h = f_widen8(xh[rnd & 1]), Z = f_widen8(xz[rnd & 1]), R = f_widen8(xr[rnd & 1]);
+            const V8 h = f_widen8(*reinterpret_cast<const u32x4_t*>(Rp + plane_off(row, c)));
+            const V8 Z = f_widen8(xz[rnd & 1]), R = f_widen8(xr[rnd & 1]);
             V8 drp, dh;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
