@@ -429,7 +429,9 @@ def main():
     del g
     opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)   # run.py:145
     params = list(model.parameters())
-    inv_count = 1.0 / float(gnodes * O)
+    # run.py accumulates the gradients of an epoch's snapshots (run.py:178-194): the model's backward adds into .grad itself (one
+    # multi-tensor add per step instead of one autograd add per parameter; same values, functional.py)
+    R.functional.set_grad_accumulation_in_backward(os.environ.get("REGT_ACC_IN_BACKWARD", "1") != "0")      # (=0: A/B)
     counter = [0]                             # ONE monotonically increasing step index over warm-up, timed loop and extra legs
     if pipe is not None:
         pipe.submit(0, xs[0])
@@ -447,7 +449,7 @@ def main():
             xp_ext = pipe.acquire(i % 2)
             pipe.submit((i + 1) % 2, xs[(i + 1) % n_snap])
             pred, _ = model.forward_packed(xp_ext, graph)
-        loss = ((pred - y) ** 2).sum() * inv_count        # mean over the GLOBAL graph (run.py:180)
+        loss = R.functional.mse_loss(pred, y, gnodes * O)   # mean over the GLOBAL graph (run.py:180): value + gradient in one kernel
         loss.backward()
         if pipe is not None:
             pipe.release(i % 2)

@@ -501,11 +501,20 @@ int launch_sum_region_blocks(const float* W, float* S, int C, int R, hipStream_t
 }
 
 // loss = scale * sum (pred - y)^2 ;  dpred = 2 * scale * (pred - y)     (scale = 1 / (N_global * O))
+// Up to 256 workgroups, each a contiguous chunk; the last one to finish (ticket counter) adds the per-workgroup sums in index
+// order -- the same result whatever the execution order.  Scratch: one of 64 static slots per call (calls in flight on different
+// streams do not share one).
+constexpr int MSE_MAX_BLOCKS = 256, MSE_SLOTS = 64;
+__device__ float g_mse_part[MSE_SLOTS][MSE_MAX_BLOCKS];
+__device__ unsigned g_mse_ticket[MSE_SLOTS];
 __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const float* y, float* dpred, float* loss_out,
-                                                       long n, float scale) {
+                                                       long n, float scale, int slot) {
     __shared__ float red[256];
+    __shared__ bool last;
+    const long per = (n + gridDim.x - 1) / gridDim.x;
+    const long i0 = (long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
     float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) {
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
         float d = pred[i] - y[i];
         if (dpred) dpred[i] = 2.0f * scale * d;
         s += d * d;
@@ -516,11 +525,33 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const float* pred, const 
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && loss_out) *loss_out = red[0] * scale;
+    if (!loss_out) return;
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) *loss_out = red[0] * scale;
+        return;
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&g_mse_part[slot][blockIdx.x], red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(&g_mse_ticket[slot], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += __hip_atomic_load(&g_mse_part[slot][b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *loss_out = tot * scale;
+        g_mse_ticket[slot] = 0;
+    }
 }
 
 int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st) {
-    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(256), 0, st, pred, y, dpred, loss_out, n, scale);
+    static unsigned next_slot = 0;
+    long blocks = (n + 2047) / 2048;             // >= 8 elements per thread before a second workgroup pays
+    if (blocks > MSE_MAX_BLOCKS) blocks = MSE_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    const int slot = (int)(next_slot++ % MSE_SLOTS);
+    hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, y, dpred, loss_out, n, scale, slot);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

@@ -111,6 +111,22 @@ def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
     return g
 
 
+# run.py accumulates the gradients of all snapshots of an epoch before one optimiser step (run.py:178-194): with autograd doing the
+# accumulation every backward ends in one `p.grad += g` kernel per parameter (21 launches of ~6 us each).  With this switch on,
+# RegTGCNFunction.backward adds its gradients to the existing `.grad` tensors itself -- ONE multi-tensor add -- and returns None
+# for the parameters (autograd then has nothing left to accumulate); a parameter without `.grad` receives this call's gradient
+# tensor directly.  Same values bit for bit (`tests/test_gpu_model.py`).  Off by default: `torch.autograd.grad(...)` and tensor
+# hooks on the parameters would see no gradient; `train.py` and `bench.py` (plain `loss.backward()` loops) switch it on.
+_ACCUMULATE_IN_BACKWARD = False
+
+
+def set_grad_accumulation_in_backward(flag: bool) -> bool:
+    """Returns the previous setting."""
+    global _ACCUMULATE_IN_BACKWARD
+    prev, _ACCUMULATE_IN_BACKWARD = _ACCUMULATE_IN_BACKWARD, bool(flag)
+    return prev
+
+
 class RegTGCNFunction(torch.autograd.Function):
     """(x, *params) -> (pred (N,O), hidden (N,C)); whole-model forward and backward in HIP."""
 
@@ -128,6 +144,7 @@ class RegTGCNFunction(torch.autograd.Function):
         names = param_names(regional)
         if len(params) != len(names):
             raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
+        ctx.leaf_params = params                 # the caller's tensors (before any padding): whose .grad an accumulating backward updates
         for n_, p_ in zip(names, params):
             if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
                 raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
@@ -230,7 +247,46 @@ class RegTGCNFunction(torch.autograd.Function):
             for n_ in F_WIDE_PARAMS:
                 if n_ in grads:
                     grads[n_] = grads[n_][:, :ctx.f_real].contiguous()
+        leaves = ctx.leaf_params
+        if _ACCUMULATE_IN_BACKWARD and all(p_.is_leaf and p_.requires_grad for p_ in leaves):
+            have, new = [], []
+            for n_, p_ in zip(names, leaves):
+                if p_.grad is None:
+                    p_.grad = grads[n_]          # (a view of this call's buffer, which nothing else refers to)
+                else:
+                    have.append(p_.grad)
+                    new.append(grads[n_])
+            if have:
+                torch._foreach_add_(have, new)
+            return (None, None, None, None, None) + (None,) * len(names)
         return (None, None, None, None, None) + tuple(grads[n_] for n_ in names)
+
+
+class MseLossFunction(torch.autograd.Function):
+    """sum((pred - y)^2) / global_count and its gradient in one kernel (regt_mse_loss_grad; run.py:180 with the mean taken over the
+    GLOBAL graph: a region shard passes the global element count)."""
+
+    @staticmethod
+    def forward(ctx, pred: torch.Tensor, y: torch.Tensor, global_count: int):
+        lib = _lib.load()
+        if not pred.is_cuda or pred.dtype != torch.float32 or y.dtype != torch.float32 or pred.shape != y.shape:
+            raise ValueError("mse_loss: pred and y must be float32 CUDA tensors of one shape")
+        pred, y = pred.contiguous(), y.contiguous()
+        dpred = torch.empty_like(pred)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        _lib.check(lib.regt_mse_loss_grad(_lib.ptr(pred), _lib.ptr(y), _lib.ptr(dpred), _lib.ptr(loss), pred.numel(), int(global_count),
+                                          _stream()), "regt_mse_loss_grad")
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None, None
+
+
+def mse_loss(pred: torch.Tensor, y: torch.Tensor, global_count: Optional[int] = None) -> torch.Tensor:
+    return MseLossFunction.apply(pred, y, pred.numel() if global_count is None else global_count)
 
 
 class FusedTrainStep:

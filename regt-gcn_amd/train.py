@@ -21,6 +21,7 @@ from typing import List, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import functional as F_
 from . import nn as rnn
 from .data import snapshot_windows
 from .dist import HaloPipeline, Shard, allreduce_gradients, allreduce_sum
@@ -41,11 +42,17 @@ def train_epoch(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], g
         optimizer.step()
         stepper.zero_grad()
         return losses[-1][0], [l[0] for l in losses]
-    for x, y in zip(xs, ys):
-        out, _ = model.forward_prepared(x, graph)
-        loss = torch.mean((out - y) ** 2)
-        loss.backward()
-        losses.append(loss.detach())
+    # (the gradients of the epoch's snapshots add up in .grad, run.py:178-194: the model's backward does that addition itself, one
+    # multi-tensor add instead of one autograd add per parameter -- functional.set_grad_accumulation_in_backward)
+    prev = F_.set_grad_accumulation_in_backward(True)
+    try:
+        for x, y in zip(xs, ys):
+            out, _ = model.forward_prepared(x, graph)
+            loss = F_.mse_loss(out, y)               # torch.mean((out - y) ** 2), run.py:180, value and gradient in one kernel
+            loss.backward()
+            losses.append(loss.detach())
+    finally:
+        F_.set_grad_accumulation_in_backward(prev)
     allreduce_gradients(list(model.parameters()))
     optimizer.step()
     optimizer.zero_grad()
@@ -72,15 +79,19 @@ def train_epoch_sharded(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Te
     losses = []
     if len(xs):
         pipe.submit(0, xs[0])
-    for i, (x, y) in enumerate(zip(xs, ys)):
-        buf = pipe.acquire(i % 2)
-        if i + 1 < len(xs):
-            pipe.submit((i + 1) % 2, xs[i + 1])
-        out, _ = model.forward_packed(buf, shard.graph)
-        loss = ((out - y) ** 2).sum() / float(global_nodes * y.shape[1])
-        loss.backward()
-        pipe.release(i % 2)
-        losses.append(loss.detach())
+    prev = F_.set_grad_accumulation_in_backward(True)
+    try:
+        for i, (x, y) in enumerate(zip(xs, ys)):
+            buf = pipe.acquire(i % 2)
+            if i + 1 < len(xs):
+                pipe.submit((i + 1) % 2, xs[i + 1])
+            out, _ = model.forward_packed(buf, shard.graph)
+            loss = F_.mse_loss(out, y, global_nodes * y.shape[1])
+            loss.backward()
+            pipe.release(i % 2)
+            losses.append(loss.detach())
+    finally:
+        F_.set_grad_accumulation_in_backward(prev)
     allreduce_gradients(list(model.parameters()), group)
     tot = allreduce_sum(torch.stack(losses), group)
     optimizer.step()

@@ -470,3 +470,49 @@ def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra)
            "GAT": R.GATTemporal}[a.model]
     cls(8, n, 6, 1).load_state_dict(sd, strict=True)
     assert all(bool(torch.isfinite(v).all()) for v in sd.values())
+
+
+def test_gradient_accumulation_inside_backward_equals_autograd_accumulation():
+    """functional.set_grad_accumulation_in_backward: the model's backward adds into .grad itself (one multi-tensor add) instead of
+    autograd's one add per parameter -- run.py:178-194 accumulates over the epoch's snapshots.  Same values bit for bit, for
+    grads that exist (zero_grad(set_to_none=False)) and for grads that do not (first step after zero_grad())."""
+    import regtgcn_amd as R
+    n, e, regions, f, t, o = 900, 7000, 3, 8, 6, 2
+    ei, ri, rw, _ = _synthetic(n, e, regions, f, t, seed=4)
+    snaps = R.data.synthetic_snapshots(n, f, t, o, 3, seed=4)
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=5)
+    out = {}
+    for flag in (False, True):
+        prev = R.functional.set_grad_accumulation_in_backward(flag)
+        try:
+            mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+            mod.load_state_dict(p, strict=True)
+            mod = mod.cuda()
+            graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+            for x, y in snaps:                                    # three snapshots accumulate
+                pred, _h = mod.forward_prepared(x.cuda(), graph)
+                torch.mean((pred - y.cuda()) ** 2).backward()
+            out[flag] = {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}
+        finally:
+            R.functional.set_grad_accumulation_in_backward(prev)
+    assert set(out[False]) == set(out[True]) and len(out[True]) > 15
+    for k in out[False]:
+        assert torch.equal(out[False][k], out[True][k]), k
+
+
+@pytest.mark.parametrize("n,o,gc", [(104, 1, None), (100_000, 1, None), (4097, 3, 50_000)])
+def test_mse_loss_function(n, o, gc):
+    """functional.mse_loss (regt_mse_loss_grad: value + gradient in one kernel, fixed summation order) vs torch.mean((out - y)**2),
+    run.py:180 -- with the global element count of a region shard."""
+    import regtgcn_amd as R
+    g = torch.Generator().manual_seed(n)
+    pred = torch.randn(n, o, generator=g).cuda().requires_grad_(True)
+    y = torch.rand(n, o, generator=g).cuda()
+    cnt = n * o if gc is None else gc
+    loss = R.functional.mse_loss(pred, y, gc)
+    loss.backward()
+    want = ((pred.detach().double() - y.double()) ** 2).sum() / cnt
+    assert abs(float(loss) - float(want)) <= 2e-6 * float(want)
+    np.testing.assert_allclose(pred.grad.cpu().numpy(), (2.0 * (pred.detach() - y) / cnt).cpu().numpy(), rtol=1e-6, atol=1e-12)
+    again = R.functional.mse_loss(pred.detach(), y, gc)
+    assert float(again) == float(loss)                           # fixed summation order: bit-reproducible

@@ -39,9 +39,15 @@ xp = torch.rand(sh.topo.x_rows, T, F, device=dev)
 y = torch.rand(n_local, O, device=dev)
 inv = 1.0 / float(gn * O)
 
+# the step of bench.py / train.py: library MSE (value + gradient in one kernel), gradient accumulation inside the model's backward
+# (REGT_ACC_IN_BACKWARD=0: autograd's per-parameter adds and the torch loss expression, for A/B)
+ACC = os.environ.get("REGT_ACC_IN_BACKWARD", "1") != "0"
+R.functional.set_grad_accumulation_in_backward(ACC)
+
+
 def step():
     pred, _ = model.forward_packed(xp, sh.graph)
-    loss = ((pred - y) ** 2).sum() * inv
+    loss = R.functional.mse_loss(pred, y, gn * O) if ACC else ((pred - y) ** 2).sum() * inv
     loss.backward()
     return loss
 
