@@ -145,6 +145,8 @@ class RegTGCNFunction(torch.autograd.Function):
         if len(params) != len(names):
             raise ValueError(f"expected {len(names)} parameter tensors, got {len(params)}")
         ctx.leaf_params = params                 # the caller's tensors (before any padding): whose .grad an accumulating backward updates
+        ctx.set_materialize_grads(False)         # an output the loss does not use arrives as None in backward, not as a tensor of zeros
+                                                 # (N x C floats filled and read back for nothing: `hidden` in every training loop)
         for n_, p_ in zip(names, params):
             if p_.dtype != torch.float32 or not p_.is_cuda or not p_.is_contiguous():
                 raise ValueError(f"parameter {n_} must be a contiguous float32 CUDA tensor")
