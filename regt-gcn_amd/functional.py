@@ -423,6 +423,7 @@ class CellFunction(torch.autograd.Function):
                                          _lib.ptr(hidden), _lib.ptr(handle.ws), wsb, _stream()), "regt_cell_forward")
         ctx.op, ctx.dims, ctx.ws_handle, ctx.wsb = op, dims, handle, wsb
         ctx.save_for_backward(hidden, h_in, *params)
+        ctx.set_materialize_grads(False)         # an unused output (hidden) arrives as None in backward, not as zeros
         return pred, hidden
 
     @staticmethod
@@ -516,6 +517,7 @@ class Cell0Function(torch.autograd.Function):
                                           _stream()), "regt_cell0_forward")
         ctx.dims, ctx.args, ctx.ws_handle, ctx.wsb = dims, args, handle, wsb
         ctx.save_for_backward(hidden, a_z, a_h, gz, gh, cz, ch, att, l1w, l1b, l2w, l2b)
+        ctx.set_materialize_grads(False)         # an unused output (hidden) arrives as None in backward, not as zeros
         return pred, hidden
 
     @staticmethod
@@ -569,6 +571,7 @@ class ZeroGradAnchor(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, hidden, *dead):
         ctx.shapes = [(d.shape, d.device) for d in dead]
+        ctx.set_materialize_grads(False)         # the unused output's gradient stays None on its way to the cell's backward
         return pred.view_as(pred), hidden.view_as(hidden)
 
     @staticmethod
