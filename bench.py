@@ -80,6 +80,8 @@ def parse():
                     help="N = 1 only: run the region-shard code path (packed input, halo pipeline, RCCL calls) with a 1-rank "
                          "process group -- a rehearsal of what N > 1 executes, not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg1-cpu-epoch", action="store_true",
+                    help="cpu_baseline leg only (no GPU): time the oracle over one epoch of the TPIMS fixture (SURVEY 8(d), cfg-1) and exit")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary bf16x3-split / bf16 measurements")
     ap.add_argument("--no-tpims-leg", action="store_true", help="skip the secondary TPIMS-scale (configs[1]) measurement")
     ap.add_argument("--no-cfg5-leg", action="store_true",
@@ -101,6 +103,47 @@ def host_info():
         pass
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "affinity_cpus": avail}
+
+
+def cfg1_cpu_epoch():
+    """SURVEY 8(d), cfg-1 -- part of the cpu_baseline leg (the only place outside tests/ that may run the oracle): the reference CPU
+    path (oracle = op-for-op restatement, run.py:163-226 loop semantics) timed over one EPOCH of the TPIMS fixture -- every window,
+    train split (forward + loss + backward, one RMSprop step at the end) and test split (forward only) at --tr 0.2 as in
+    scripts/RegionalTemporalGCN.sh -- at T = 6 and T = 12, with torch's default thread count and with one thread.  The authors'
+    14-day dataset has 2010 windows per epoch (402 train / 1608 test); the fixture holds 60 timesteps, so the per-snapshot rates are
+    what an epoch of any length costs.    python bench.py --cfg1-cpu-epoch > profiles/rNN_cfg1_cpu_epoch.txt"""
+    from oracle import loop as L, model as M
+    z = np.load(os.path.join(ROOT, "tests", "golden", "tpims_fixture.npz"))
+    fx = {k: torch.from_numpy(z[k]) for k in z.files if z[k].ndim > 0}
+    regs = ("IA", "KS", "KY", "OH", "WI")
+    ri, rw = [fx[f"edge_{r}_index"] for r in regs], [fx[f"edge_{r}_attr"] for r in regs]
+    n = fx["node_data"].shape[0]
+    cpu = "unknown"
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            cpu = line.split(":", 1)[1].strip()
+            break
+    default_threads = torch.get_num_threads()
+    print(f"host: {cpu}; os.cpu_count() = {os.cpu_count()}; affinity = {len(os.sched_getaffinity(0))}; torch default threads = {default_threads}")
+    for t_in in (6, 12):
+        xs, ys = L.make_windows(fx["node_data"], t_in, 1)
+        (tx, ty), (vx, vy) = L.split(xs, ys, 0.2)
+        for threads in (default_threads, 1):
+            torch.set_num_threads(threads)
+            p = {k: v.clone().requires_grad_(True) for k, v in M.init_params("RegionalTemporalGCN", 8, t_in, 1, num_nodes=n, seed=0).items()}
+            opt = torch.optim.RMSprop(list(p.values()), lr=1e-3, weight_decay=1e-4)
+            fwd = lambda q, x: M.regional_temporal_gcn(q, x, fx["edge_index"], ri, rw)      # noqa: E731
+            L.train_epoch(p, fwd, tx[:2], ty[:2], opt)                      # warm-up
+            t0 = time.perf_counter()
+            L.train_epoch(p, fwd, tx, ty, opt)
+            t_train = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            L.evaluate(p, fwd, vx, vy)
+            t_test = time.perf_counter() - t0
+            tr, te = len(tx) / t_train, len(vx) / t_test
+            print(f"T={t_in:2d} O=1 threads={threads:3d}: train {len(tx)} snapshots in {t_train:6.2f} s = {tr:6.1f} snapshots/s (fwd+bwd); "
+                  f"test {len(vx)} snapshots in {t_test:6.2f} s = {te:6.1f} snapshots/s (fwd); a 402 + 1608 epoch = {402 / tr + 1608 / te:6.1f} s")
+    torch.set_num_threads(default_threads)
 
 
 def cpu_baseline(nodes, edges, regions, F, T, O, seed=42, model_regions=None, scale_regions=1, note=""):
@@ -340,6 +383,9 @@ def main():
     nodes, edges, regions, F, T, O = wl["nodes"], wl["edges"], wl["regions"], wl["F"], wl["T"], wl["O"]
     mode = wl["mode"] if args.gemm_mode is None else args.gemm_mode
     dtype = {0: "fp32", 1: "fp32", 2: "bf16"}[mode]
+    if args.cfg1_cpu_epoch:
+        cfg1_cpu_epoch()
+        return
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(nodes, edges, regions, F, T, O)))
         return
