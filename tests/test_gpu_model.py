@@ -516,3 +516,37 @@ def test_mse_loss_function(n, o, gc):
     np.testing.assert_allclose(pred.grad.cpu().numpy(), (2.0 * (pred.detach() - y) / cnt).cpu().numpy(), rtol=1e-6, atol=1e-12)
     again = R.functional.mse_loss(pred.detach(), y, gc)
     assert float(again) == float(loss)                           # fixed summation order: bit-reproducible
+
+
+@pytest.mark.parametrize("mode,f", [(0, 32), (2, 64)])
+def test_training_steps_are_bit_reproducible_with_the_side_stream(mode, f):
+    """Twenty forward + backward passes on one snapshot: outputs and every gradient identical each time.  The weight compositions,
+    the head's weight gradients and the attention-gradient tail run on the library's side stream (forked / joined by events inside
+    regt_forward / regt_backward): a missing join would show up here as a run-to-run difference.  fp32 path and the fused bf16 path."""
+    import regtgcn_amd as R
+    lib = R.load_library()
+    prev = lib.regt_set_gemm_mode(mode)
+    try:
+        n, e, regions, t, o = 6000, 50000, 8, 12, 1
+        ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=9)
+        y = torch.rand(n, o, generator=torch.Generator().manual_seed(2)).cuda()
+        p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=6)
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        xs = x.cuda()
+        first = None
+        for it in range(20):
+            mod.zero_grad(set_to_none=True)
+            pred, hidden = mod.forward_prepared(xs, graph)
+            R.functional.mse_loss(pred, y).backward()
+            snap = [pred.detach().clone(), hidden.detach().clone()] + [q.grad.clone() for q in mod.parameters() if q.grad is not None]
+            if first is None:
+                first = snap
+            else:
+                assert len(snap) == len(first)
+                for k, (a_, b_) in enumerate(zip(snap, first)):
+                    assert torch.equal(a_, b_), (it, k)
+    finally:
+        lib.regt_set_gemm_mode(prev)
