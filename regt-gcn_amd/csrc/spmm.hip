@@ -29,11 +29,80 @@ __global__ void pack_x_kernel(const float* __restrict__ x, float* __restrict__ x
     }
 }
 
+// The same transposition staged through LDS: a workgroup takes NB whole nodes (NB * F * T floats, contiguous on both sides), reads
+// them with coalesced 16-byte loads, and writes 16-byte pieces of (node, period) rows.  NTL: the snapshot is read exactly once ->
+// non-temporal loads, so that the lines of x do not displace the packed rows (which the aggregation reads next) from the
+// Infinity Cache.  F % 4 == 0, NB * F * T <= PACK_LDS_FLOATS.
+constexpr int PACK_LDS_FLOATS = 4096;
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void pack_x_lds_kernel(const float* __restrict__ x, float* __restrict__ xp, int N, int F, int T, int NB) {
+    __shared__ float4 tile4[PACK_LDS_FLOATS / 4];
+    float* tile = reinterpret_cast<float*>(tile4);
+    const int FT = F * T, F4 = F / 4;
+    for (long n0 = (long)blockIdx.x * NB; n0 < N; n0 += (long)gridDim.x * NB) {
+        const int nb = N - n0 < NB ? (int)(N - n0) : NB;
+        const int tot4 = nb * FT / 4;                    // FT % 4 == 0 since F % 4 == 0
+        const float4* src = reinterpret_cast<const float4*>(x + n0 * FT);
+        for (int i = threadIdx.x; i < tot4; i += 256) {
+            float4 v;
+            if (NTL) {
+                const float* s = reinterpret_cast<const float*>(src + i);
+                v.x = __builtin_nontemporal_load(s); v.y = __builtin_nontemporal_load(s + 1);
+                v.z = __builtin_nontemporal_load(s + 2); v.w = __builtin_nontemporal_load(s + 3);
+            } else {
+                v = src[i];
+            }
+            tile4[i] = v;
+        }
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(xp + n0 * FT);
+        for (int o = threadIdx.x; o < tot4; o += 256) {  // o = (node, t, f4)
+            const int n = o / (T * F4), rem = o - n * T * F4;
+            const int t = rem / F4, f = (rem - t * F4) * 4;
+            const float* b = tile + n * FT + f * T + t;
+            const float4 v = make_float4(b[0], b[T], b[2 * T], b[3 * T]);
+            if (NTS) {
+                float* d = reinterpret_cast<float*>(dst + o);
+                __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
+                __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
+            } else {
+                dst[o] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void pack_x_nt_kernel(const float* __restrict__ x, float* __restrict__ xp, long N, int F, int T) {
+    const long total = N * F * T;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        long n = o / ((long)F * T);
+        int rem = (int)(o - n * F * T);
+        int t = rem / F, f = rem - t * F;
+        xp[o] = __builtin_nontemporal_load(x + n * F * T + (long)f * T + t);
+    }
+}
+
+// REGT_PACK: 0 element-wise (round 1), 1 element-wise with nt loads, 2 LDS-staged, 3 LDS-staged + nt loads (default), 4 = 3 + nt stores
 int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st) {
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("REGT_PACK"); variant = e ? atoi(e) : 3; }
     long total = (long)N * F * T;
+    const int FT = F * T;
+    if (variant >= 2 && F % 4 == 0 && FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
+        const int NB = PACK_LDS_FLOATS / FT;
+        long blocks = cdiv((long)N, NB);
+        if (blocks > 256L * 16) blocks = 256L * 16;
+        if (variant == 2) hipLaunchKernelGGL((pack_x_lds_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
+        else if (variant == 4) hipLaunchKernelGGL((pack_x_lds_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
+        else hipLaunchKernelGGL((pack_x_lds_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
+        REGT_CHECK_LAUNCH();
+        return REGT_OK;
+    }
     int blocks = cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pack_x_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
+    if (variant == 1) hipLaunchKernelGGL(pack_x_nt_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
+    else hipLaunchKernelGGL(pack_x_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
