@@ -126,7 +126,9 @@ __global__ void pack_x_bf16_kernel(const float* __restrict__ x, uint4* __restric
         const int t = (int)(nt - n * T);
         const float* s = x + n * F * T + (long)f0 * T + t;
         uint4 v;
-        v.x = pk2(s[0], s[T]); v.y = pk2(s[2L * T], s[3L * T]); v.z = pk2(s[4L * T], s[5L * T]); v.w = pk2(s[6L * T], s[7L * T]);
+#define REGT_NTL(k) __builtin_nontemporal_load(s + (k) * (long)T)      /* the snapshot is read once: keep it out of the caches' way */
+        v.x = pk2(REGT_NTL(0), REGT_NTL(1)); v.y = pk2(REGT_NTL(2), REGT_NTL(3)); v.z = pk2(REGT_NTL(4), REGT_NTL(5)); v.w = pk2(REGT_NTL(6), REGT_NTL(7));
+#undef REGT_NTL
         xp[o] = v;
     }
 }
@@ -142,8 +144,12 @@ int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_
 // n8 groups of 8 fp32 -> 8 bf16 (packed rows handed over as fp32 by a caller of regt_forward_packed)
 __global__ void cvt_rows_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long n8) {
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n8; o += (long)gridDim.x * blockDim.x) {
-        const float4 a = src[2 * o], b = src[2 * o + 1];
-        dst[o] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+        // read once: non-temporal, so that the fp32 rows do not displace the bf16 rows (read next by the aggregation) from the Infinity Cache
+        const float* s = reinterpret_cast<const float*>(src + 2 * o);
+        float a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = __builtin_nontemporal_load(s + i);
+        dst[o] = make_uint4(pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7]));
     }
 }
 int launch_cvt_rows_bf16(const float* src, void* dst, long n, hipStream_t st) {
@@ -332,12 +338,13 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
 // The regional Laplacian rows are (almost) a subset of the full-graph rows: the same neighbour row
 // x[col] feeds both A_hat x and L~ x.  With a merged CSR that carries two weights per entry, one gather
 // serves both outputs -- half the gather volume of the stacked operator.  Same XCD/panel schedule as above.
-template <int PL, int IDX, bool NTS>   // PL lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two);
-                                        // IDX (<= PL) CSR entries fetched per index load; NTS: streaming output stores
+template <int PL, int IDX, bool NTS, bool CNT = false>   // PL lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two);
+                                        // IDX (<= PL) CSR entries fetched per index load; NTS: streaming output stores;
+                                        // CNT: non-temporal loads of the CSR entries (A/B: REGT_SPMM_CSRNT)
 __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                               const float* __restrict__ val_a, const float* __restrict__ val_l,
                                                               const float* __restrict__ X, float* __restrict__ YA,
-                                                              float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb) {
+                                                              float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb, int ldx4) {
     static_assert(IDX % 8 == 0 && IDX <= PL, "index chunk is a multiple of the 8-gather round and fits the lane group");
     constexpr int ROWS = 256 / PL;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
@@ -357,7 +364,10 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
         const int n = end - base < IDX ? end - base : IDX;
         int myc = 0;
         float mya = 0.f, myl = 0.f;
-        if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+        if (gl < n) {
+            if (CNT) { myc = __builtin_nontemporal_load(col + base + gl); mya = __builtin_nontemporal_load(val_a + base + gl); myl = __builtin_nontemporal_load(val_l + base + gl); }
+            else { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
+        }
 #pragma unroll
         for (int r = 0; r < IDX / 8; ++r) {
             if (r * 8 < n) {
@@ -369,7 +379,7 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
                     const int c = __shfl(myc, r * 8 + e, PL);
                     va[e] = __shfl(mya, r * 8 + e, PL);
                     vl[e] = __shfl(myl, r * 8 + e, PL);
-                    x[e] = r * 8 + e < n ? X4[(long)c * W4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    x[e] = r * 8 + e < n ? X4[(long)c * ldx4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -690,15 +700,19 @@ int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, co
     const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
     const long grid = 8L * npanels * nrb;
     REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual: grid too large");
-    static int nt_env = -1, idx_env = -1;
+    static int nt_env = -1, idx_env = -1, cnt_env = -1, xld_env = -1;
     if (nt_env < 0) { const char* e = getenv("REGT_SPMM_NT"); nt_env = e ? atoi(e) : 1; }
     if (idx_env < 0) { const char* e = getenv("REGT_SPMM_IDX"); idx_env = e ? atoi(e) : 16; }
-#define REGT_DUAL(PLL, IDXX, NTT)                                                                                              \
-    hipLaunchKernelGGL((spmm_dual_panel_kernel<PLL, IDXX, NTT>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, \
-                       X, YA, YL, nnodes, W4, npanels, nrb)
+    if (cnt_env < 0) { const char* e = getenv("REGT_SPMM_CSRNT"); cnt_env = e ? atoi(e) : 0; }
+    if (xld_env < 0) { const char* e = getenv("REGT_SPMM_XLD"); xld_env = e ? atoi(e) : 0; }   // experiment: row stride of X in floats
+    const int ldx4 = xld_env > 0 ? xld_env / 4 : W4;
+#define REGT_DUAL(PLL, IDXX, NTT, ...)                                                                                              \
+    hipLaunchKernelGGL((spmm_dual_panel_kernel<PLL, IDXX, NTT, ##__VA_ARGS__>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, \
+                       X, YA, YL, nnodes, W4, npanels, nrb, ldx4)
     if (wide) {
         if (nt_env == 0) REGT_DUAL(16, 8, false);
         else if (idx_env == 8) REGT_DUAL(16, 8, true);
+        else if (cnt_env) REGT_DUAL(16, 16, true, true);
         else REGT_DUAL(16, 16, true);
     } else {
         if (nt_env == 0) REGT_DUAL(8, 8, false);

@@ -242,7 +242,30 @@ class RegionalTemporalGCN(_FusedModel):
         _need_cuda(x)
         return self._run(x, graph)
 
-    def forward(self, x, edge_index, *regions):
+    # the reference's parameter names, in its order (models/RegionalTemporalGCN.py:25-26): accepted as keywords too
+    REF_KEYWORDS = ("IAedge_index", "KSedge_index", "KYedge_index", "OHedge_index", "WIedge_index",
+                    "IAedge_attr", "KSedge_attr", "KYedge_attr", "OHedge_attr", "WIedge_attr")
+
+    def forward(self, x, edge_index, *regions, **named):
+        if named:
+            # keyword call with the reference's names (any prefix of the ten may still be positional, as in Python's own binding)
+            unknown = [k for k in named if k not in self.REF_KEYWORDS]
+            if unknown:
+                raise TypeError(f"forward() got an unexpected keyword argument '{unknown[0]}'")
+            if self.num_regions != 5:
+                raise TypeError("the reference's keyword names cover its 5 regions; this model was built for "
+                                f"{self.num_regions} -- pass the region tensors positionally or as two lists")
+            if len(regions) > len(self.REF_KEYWORDS) or (len(regions) == 2 and isinstance(regions[0], (list, tuple))):
+                raise TypeError("forward(): keyword region arguments cannot be mixed with the list form")
+            bound = list(regions)
+            for k in self.REF_KEYWORDS[len(regions):]:
+                if k not in named:
+                    raise TypeError(f"forward() missing 1 required positional argument: '{k}'")
+                bound.append(named[k])
+            for k in self.REF_KEYWORDS[:len(regions)]:
+                if k in named:
+                    raise TypeError(f"forward() got multiple values for argument '{k}'")
+            regions = tuple(bound)
         _need_cuda(x)
         if len(regions) == 2 and isinstance(regions[0], (list, tuple)):
             idx, attr = list(regions[0]), list(regions[1])

@@ -52,6 +52,17 @@ def test_modules_refuse_cpu_tensors_and_keep_reference_layout():
     m.load_state_dict(sd, strict=True)
     with pytest.raises(R.RegtError):
         m(torch.zeros(104, 8, 6), torch.zeros(2, 0, dtype=torch.long))
+    # the reference's keyword names bind like its positional parameters (models/RegionalTemporalGCN.py:25-26): a complete keyword
+    # call gets as far as the device check, a wrong name is Python's TypeError
+    z, e = torch.zeros(104, 8, 6), torch.zeros(2, 0, dtype=torch.long)
+    kw = {f"{r}edge_index": e for r in ("IA", "KS", "KY", "OH", "WI")}
+    kw.update({f"{r}edge_attr": torch.zeros(0) for r in ("IA", "KS", "KY", "OH", "WI")})
+    with pytest.raises(R.RegtError):
+        m(x=z, edge_index=e, **kw)
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        m(z, e, **kw, edge_weight=None)
+    with pytest.raises(TypeError, match="missing 1 required"):
+        m(z, e, **{k: v for k, v in kw.items() if k != "WIedge_attr"})
     t = R.TemporalGCN(node_features=8, periods=6, output_dim=3)
     assert "tgnn.linear.weight" in t.state_dict() and tuple(t.state_dict()["tgnn.linear.weight"].shape) == (256, 64)
     assert not any(k.startswith("tgnn._weight_att") for k in t.state_dict())

@@ -105,3 +105,80 @@ def test_full_configuration_identical_periods_property(R, graph):
             continue
         scale = max(float(g1[k].abs().max()), 1e-8)
         assert float((g12[k] - g1[k]).abs().max()) < 2e-4 * scale + 1e-9, k
+
+
+# ---- BASELINE configs[3]: the SAME cfg-3 graph sharded one region per GPU, at full size, without 8 GPUs -------------------------
+# The eight 1-region shards (12 500 own + ~5 300 halo rows each) are built by dist.build_shard(world=8) and executed one after
+# the other on the one GPU; a rank's halo rows are copied from the global packed snapshot (what the all-to-all delivers).  Every
+# owned prediction / hidden row must equal the single-GPU run's and the gradients summed over the ranks (= the all-reduce) must
+# equal its gradients.  Op sites: models/RegionalTemporalGCN.py:131-149, models/utils.py:163-203; SURVEY 8(e) correctness test.
+WORLD = 8
+BF16_U = 2.0 ** -9
+
+
+def _eight_shards(R, graph, mode):
+    lib = R.load_library()
+    t = 12
+    (x, y), = R.data.synthetic_snapshots(NODES, F, t, O, 1, seed=21)
+    p = M.init_params("RegionalTemporalGCN", F, t, O, num_nodes=NODES, num_regions=REGIONS, seed=22)
+    prev = lib.regt_set_gemm_mode(mode)
+    try:
+        def fresh():
+            m = R.RegionalTemporalGCN(F, NODES, t, O, num_regions=REGIONS)
+            m.load_state_dict(p)
+            return m.cuda()
+
+        full = fresh()
+        pg = full.prepare_graph(graph.edge_index.cuda(), _cuda(graph.region_index), _cuda(graph.region_attr))
+        pred_f, hid_f = full.forward_prepared(x.cuda(), pg)
+        (((pred_f - y.cuda()) ** 2).sum() / (NODES * O)).backward()
+        pred_f, hid_f = pred_f.detach(), hid_f.detach()
+        grads_f = {k: q.grad.clone() for k, q in full.named_parameters() if q.grad is not None}
+        del full, pg
+        torch.cuda.empty_cache()
+
+        sharded = fresh()
+        rpg = REGIONS // WORLD
+        bounds = np.asarray(graph.region_bounds[::rpg], dtype=np.int64)
+        owner = [r // rpg for r in range(REGIONS)]
+        xp_glob = R.ops.pack_x(x.cuda()).view(NODES, t * F)
+        worst_pred = worst_hid = 0.0
+        halo_rows = []
+        for rank in range(WORLD):
+            sh = R.dist.build_shard(graph.edge_index, graph.region_index, graph.region_attr, NODES, bounds, owner, rank, WORLD, "cuda")
+            lo, hi = sh.topo.node_lo, sh.topo.node_hi
+            assert sh.graph.region_lo == rank and sh.graph.region_hi == rank + 1          # one region per rank
+            halo_rows.append(sh.topo.halo_rows)
+            xp = torch.empty(sh.topo.x_rows, t * F, device="cuda")
+            xp[:hi - lo] = xp_glob[lo:hi]
+            xp[hi - lo:] = xp_glob[torch.from_numpy(sh.topo.halo_ids()).cuda()]
+            pred, hid = sharded.forward_packed(xp.view(sh.topo.x_rows, t, F), sh.graph)
+            worst_pred = max(worst_pred, float((pred.detach() - pred_f[lo:hi]).abs().max()))
+            worst_hid = max(worst_hid, float((hid.detach() - hid_f[lo:hi]).abs().max()))
+            (((pred - y[lo:hi].cuda()) ** 2).sum() / (NODES * O)).backward()              # .grad accumulates = all-reduce(sum)
+            del sh, xp, pred, hid
+        grads_s = {k: q.grad for k, q in sharded.named_parameters() if q.grad is not None}
+        assert set(grads_s) == set(grads_f)
+        return worst_pred, worst_hid, grads_f, grads_s, float(hid_f.abs().max()), float(pred_f.abs().max()), halo_rows
+    finally:
+        lib.regt_set_gemm_mode(prev)
+
+
+def test_configs3_eight_region_shards_fullsize_match_single_gpu_fp32(R, graph):
+    worst_pred, worst_hid, gf, gs, _, _, halo = _eight_shards(R, graph, 0)
+    assert all(3000 < h < 9000 for h in halo), halo                   # ~5 300 halo rows per 12 500-node shard
+    assert worst_pred < 1e-6 and worst_hid < 1e-6, (worst_pred, worst_hid)
+    for k in gf:
+        # sums over 1.2 M rows, split into eight partial sums in another order than the single pass
+        np.testing.assert_allclose(gs[k].cpu().numpy(), gf[k].cpu().numpy(), rtol=1e-4, atol=2e-6 * max(1.0, float(gf[k].abs().max())), err_msg=k)
+
+
+def test_configs3_eight_region_shards_fullsize_match_single_gpu_bf16(R, graph):
+    """The bf16 arithmetic (bf16 rows + fused kernels, the configs[4] code path) on the same eight shards: the sharded run against the
+    single-GPU bf16 run is held to the 8 u bar of tests/test_gpu_bf16.py (tile boundaries differ between the two, so operands can
+    round the other way) -- measured far below it."""
+    worst_pred, worst_hid, gf, gs, hscale, pscale, _ = _eight_shards(R, graph, 2)
+    assert worst_hid < 8 * BF16_U * hscale and worst_pred < 8 * BF16_U * pscale, (worst_pred, worst_hid)
+    for k in gf:
+        a, b = gs[k].double().cpu(), gf[k].double().cpu()
+        assert float((a - b).norm()) <= 8 * BF16_U * float(b.norm()) + 1e-9, k

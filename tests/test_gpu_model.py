@@ -225,6 +225,34 @@ def test_forward_is_deterministic_and_graph_is_cached(R, tpims):
     assert torch.equal(a[0], c[0])
 
 
+def test_regional_forward_accepts_the_reference_keyword_names(R, tpims):
+    """models/RegionalTemporalGCN.py:25-26 names its twelve parameters; a keyword call (all ten region arguments, or a positional
+    prefix + the rest by name, as Python binds them) gives the positional call's result, and the binding errors are Python's."""
+    n = tpims["node_data"].shape[0]
+    p = M.init_params("RegionalTemporalGCN", 8, 6, 1, num_nodes=n, seed=11)
+    mod = R.RegionalTemporalGCN(8, n, 6, 1)
+    mod.load_state_dict(p)
+    mod = mod.cuda()
+    ri, rw = region_lists(tpims)
+    x = tpims["node_data"][:, :, :6].contiguous().cuda()
+    ei = tpims["edge_index"].cuda()
+    ric, rwc = _cuda_list(ri), _cuda_list(rw)
+    want = mod(x, ei, *ric, *rwc)
+    names = ("IA", "KS", "KY", "OH", "WI")
+    kw = {f"{r}edge_index": t for r, t in zip(names, ric)}
+    kw.update({f"{r}edge_attr": t for r, t in zip(names, rwc)})
+    got = mod(x=x, edge_index=ei, **kw)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    got = mod(x, ei, ric[0], ric[1], **{k: v for k, v in kw.items() if k not in ("IAedge_index", "KSedge_index")})
+    assert torch.equal(got[0], want[0])
+    with pytest.raises(TypeError, match="unexpected keyword"):
+        mod(x, ei, **kw, edge_attr=rwc[0])
+    with pytest.raises(TypeError, match="missing 1 required"):
+        mod(x, ei, **{k: v for k, v in kw.items() if k != "OHedge_attr"})
+    with pytest.raises(TypeError, match="multiple values"):
+        mod(x, ei, ric[0], **kw)
+
+
 def test_hidden_gradient_path(R, tpims):
     """A loss on the hidden output (second return value) reaches the parameters too."""
     n = tpims["node_data"].shape[0]
