@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 5
+#define REGT_ABI_VERSION 6
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -133,7 +133,21 @@ typedef struct regt_dims {
     int32_t N, T, F, C, R, O, H1;
     int32_t regional;
     float lrelu_slope;      /* 0.01 (F.leaky_relu default, RegionalTemporalGCN.py:143) */
+    /* ABI v6 -- per-call configuration (no process state involved; zero-initialised = the process defaults):
+     * arith: GEMM arithmetic of THIS call: 0 = the process default (regt_set_gemm_mode / REGT_GEMM_MODE), 1 = fp32 MFMA,
+     *        2 = exact bf16x3 split, 3 = bf16 operands.  regt_backward must be given the value its forward ran with
+     *        (checked against what the forward stored in the workspace).
+     * flags: REGT_DIMS_* bits below. */
+    int32_t arith;
+    uint32_t flags;
 } regt_dims;
+#define REGT_ARITH_DEFAULT 0
+#define REGT_ARITH_FP32 1
+#define REGT_ARITH_BF16X3 2
+#define REGT_ARITH_BF16 3
+#define REGT_DIMS_NO_BF16_ROWS 1u   /* bf16 arithmetic without the bf16-row layout / fused forward (= regt_set_option("xbf", 0)) */
+#define REGT_DIMS_NO_FUSED_BWD 2u   /* bf16 arithmetic with the three data-gradient launches (= regt_set_option("fused_bwd", 0)) */
+#define REGT_DIMS_NO_SIDE_STREAM 4u /* every kernel of this call on `stream` itself (no library side stream) */
 
 typedef struct regt_graph {
     const int32_t* rowptr;        /* (2N+1) */

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REGT_LIB_DIR: a developer build of the same library in another directory (build.py honours the same variable), e.g. the
 # workgroup-trace build of tools/wg_trace.py; never a different implementation
 LIB_PATH = os.path.join(os.environ.get("REGT_LIB_DIR") or os.path.join(HERE, "lib"), "libregtgcn_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -26,7 +26,24 @@ class RegtError(RuntimeError):
 
 class Dims(C.Structure):
     _fields_ = [("N", C.c_int32), ("T", C.c_int32), ("F", C.c_int32), ("C", C.c_int32), ("R", C.c_int32),
-                ("O", C.c_int32), ("H1", C.c_int32), ("regional", C.c_int32), ("lrelu_slope", C.c_float)]
+                ("O", C.c_int32), ("H1", C.c_int32), ("regional", C.c_int32), ("lrelu_slope", C.c_float),
+                # ABI v6, per-call configuration (zero = process defaults): GEMM arithmetic (ARITH_*), DIMS_* flag bits
+                ("arith", C.c_int32), ("flags", C.c_uint32)]
+
+
+ARITH_DEFAULT, ARITH_FP32, ARITH_BF16X3, ARITH_BF16 = 0, 1, 2, 3
+ARITH_NAMES = {None: ARITH_DEFAULT, "default": ARITH_DEFAULT, "fp32": ARITH_FP32, "bf16x3": ARITH_BF16X3, "bf16": ARITH_BF16}
+DIMS_NO_BF16_ROWS, DIMS_NO_FUSED_BWD, DIMS_NO_SIDE_STREAM = 1, 2, 4
+
+
+def arith_code(arith) -> int:
+    """``None`` / "default" / "fp32" / "bf16x3" / "bf16" (or the REGT_ARITH_* integer) -> regt_dims.arith."""
+    if isinstance(arith, int) and not isinstance(arith, bool) and 0 <= arith <= 3:
+        return arith
+    try:
+        return ARITH_NAMES[arith]
+    except (KeyError, TypeError):
+        raise ValueError(f"arithmetic must be one of {sorted(k for k in ARITH_NAMES if k)} or None, got {arith!r}") from None
 
 
 class Graph(C.Structure):

@@ -161,16 +161,32 @@ int q_format(const void* ws) {
 // ... and, where the fused forward kernel applies (fused.hip: C = 256, F = 64, node-disjoint regions), x, A_hat x and L~ x as
 // well: the snapshot is rounded once while it is packed, the aggregation reads and writes bf16 rows (cfg-5).
 // REGT_XBF=0 keeps them fp32 and the three-launch forward (A/B timing; tests/test_gpu_fused.py compares the two bit for bit).
+// per-call switches (regt_dims.flags) of the entry point running on this thread; the process-wide options are the defaults
+thread_local unsigned t_call_flags = 0;
 int g_opt_fused_bwd = -1;
 bool fused_bwd_wanted() {
+    if (t_call_flags & REGT_DIMS_NO_FUSED_BWD) return false;
     if (g_opt_fused_bwd < 0) { const char* e = getenv("REGT_FUSED_BWD"); g_opt_fused_bwd = e ? atoi(e) : 1; }
     return g_opt_fused_bwd != 0;
 }
 int g_opt_xbf = -1;
 bool xbf_wanted() {
+    if (t_call_flags & REGT_DIMS_NO_BF16_ROWS) return false;
     if (g_opt_xbf < 0) { const char* e = getenv("REGT_XBF"); g_opt_xbf = e ? atoi(e) : 1; }
     return g_opt_xbf != 0;
 }
+// regt_dims.arith / .flags hold for the duration of one entry point on the calling thread
+struct CallScope {
+    int prev_mode;
+    unsigned prev_flags;
+    explicit CallScope(const regt_dims* d) {
+        prev_flags = t_call_flags;
+        t_call_flags = d ? d->flags : 0;
+        const int a = d ? d->arith : 0;
+        prev_mode = gemm_mode_override(a >= REGT_ARITH_FP32 && a <= REGT_ARITH_BF16 ? a - 1 : -1);
+    }
+    ~CallScope() { gemm_mode_override(prev_mode); t_call_flags = prev_flags; }
+};
 // workspace formats remembered between forward and backward (note_q_format): bit 0 = bf16 intermediates, bit 1 = bf16 rows of
 // x / A_hat x / L~ x, bit 2 = the packed input was the CALLER's bf16 buffer (else the rounded copy lives in the workspace)
 enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4 };
@@ -323,6 +339,7 @@ int check_dims(const regt_dims* d) {
     // spans three or more 64-row blocks and the order of the float atomics shows in the last bits)
     REGT_CHECK_ARG(d->T <= 255, "dims: T=%d exceeds 255 periods", d->T);
     REGT_CHECK_ARG((long)d->N * d->T < (1L << 31), "dims: N*T too large");
+    REGT_CHECK_ARG(d->arith >= REGT_ARITH_DEFAULT && d->arith <= REGT_ARITH_BF16, "dims: arith=%d is not one of REGT_ARITH_*", d->arith);
     return REGT_OK;
 }
 
@@ -568,8 +585,10 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
 // out[Nout x Nin] (+ column sums) = P^T Q over uniform chunks, reduced deterministically.
 // Weight-gradient slabs and their reductions inside one backward pass: every wgrad gets its own slab region and its
 // reduction is only recorded; flush() runs all recorded reductions in ONE launch.  A region request that does not fit
-// flushes first and starts over at the base of the slab (stream order keeps that safe).
+// flushes first and starts over at the base of the slab (stream order keeps that safe on `st`; the side stream is re-forked
+// behind the flush, side_resync).
 static int side_join(hipStream_t st);      // work forked to the library's side stream completes before any slab is reduced
+static void side_resync(hipStream_t st);
 struct ReduceQueue {
     float* base;
     long capacity, used = 0;
@@ -579,7 +598,12 @@ struct ReduceQueue {
     int take(long floats, float** out) {
         floats = (floats + 63) & ~63L;
         REGT_CHECK_ARG(floats <= capacity, "backward: weight-gradient slab of %ld floats exceeds the workspace region (%ld)", floats, capacity);
-        if (used + floats > capacity) TRY(flush());
+        if (used + floats > capacity) {
+            // the reduction just enqueued on `st` still reads the slabs: work on the side stream must not start overwriting
+            // the region handed out next before it has run (side_join only orders `st` behind the side stream)
+            TRY(flush());
+            side_resync(st);
+        }
         *out = base + used;
         used += floats;
         return REGT_OK;
@@ -614,27 +638,64 @@ struct ReduceQueue {
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
-    int enabled = -1;
     bool forked = false;
 };
-static SideStream g_side;
+// One side stream (+ its event pair and fork state) per (device, launch stream): two launch streams, two devices or two host
+// threads with streams of their own never share fork / join state.  (Two threads enqueueing on the SAME launch stream at once
+// are the caller's race, as for any stream.)  The table is guarded by a mutex; HIP calls on the entry run under it, too -- they
+// only enqueue.
+static std::mutex g_side_mu;
+static std::map<std::pair<int, hipStream_t>, SideStream> g_sides;
+static int g_side_enabled = -1;
+static const size_t SIDE_MAX_STREAMS = 64;
 static hipStream_t side_fork(hipStream_t st) {       // returns the stream to launch on (st itself when the side stream is off)
-    if (g_side.enabled < 0) { const char* e = getenv("REGT_SIDE_STREAM"); g_side.enabled = e ? atoi(e) : 1; }
-    if (!g_side.enabled || g_graph_mode > 0) return st;
-    if (!g_side.s) {
-        if (hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess) { g_side.enabled = 0; g_side.s = nullptr; (void)hipGetLastError(); return st; }
+    if (t_call_flags & REGT_DIMS_NO_SIDE_STREAM) return st;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (g_side_enabled < 0) { const char* e = getenv("REGT_SIDE_STREAM"); g_side_enabled = e ? atoi(e) : 1; }
+    if (!g_side_enabled || g_graph_mode > 0) return st;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return st; }
+    const auto key = std::make_pair(dev, st);
+    auto it = g_sides.find(key);
+    if (it == g_sides.end()) {
+        if (g_sides.size() >= SIDE_MAX_STREAMS) return st;        // a caller cycling through many streams: stay on the launch stream
+        SideStream ns;
+        if (hipStreamCreateWithFlags(&ns.s, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ns.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ns.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ns.s) (void)hipStreamDestroy(ns.s);
+            if (ns.fork) (void)hipEventDestroy(ns.fork);
+            return st;
+        }
+        it = g_sides.emplace(key, ns).first;
     }
-    if (hipEventRecord(g_side.fork, st) != hipSuccess || hipStreamWaitEvent(g_side.s, g_side.fork, 0) != hipSuccess) { (void)hipGetLastError(); return st; }
-    g_side.forked = true;
-    return g_side.s;
+    SideStream& ss = it->second;
+    if (hipEventRecord(ss.fork, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.fork, 0) != hipSuccess) { (void)hipGetLastError(); return st; }
+    ss.forked = true;
+    return ss.s;
 }
 static int side_join(hipStream_t st) {
-    if (!g_side.forked) return REGT_OK;
-    g_side.forked = false;
-    REGT_CHECK_HIP(hipEventRecord(g_side.join, g_side.s));
-    REGT_CHECK_HIP(hipStreamWaitEvent(st, g_side.join, 0));
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return REGT_OK; }
+    auto it = g_sides.find(std::make_pair(dev, st));
+    if (it == g_sides.end() || !it->second.forked) return REGT_OK;
+    SideStream& ss = it->second;
+    ss.forked = false;
+    REGT_CHECK_HIP(hipEventRecord(ss.join, ss.s));
+    REGT_CHECK_HIP(hipStreamWaitEvent(st, ss.join, 0));
     return REGT_OK;
+}
+// the side stream (if this launch stream has one in use) continues only after everything enqueued on `st` so far: used when a slab
+// region is handed out again after an overflow flush -- the reduction that still reads it runs on `st`
+static void side_resync(hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (g_sides.find(std::make_pair(dev, st)) == g_sides.end()) return;
+    }
+    (void)side_fork(st);
 }
 
 int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int Nout, const float* Q, long ldq, int Nin, int q_relu,
@@ -1057,6 +1118,7 @@ static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, co
                               const float* xp_ext, int32_t x_rows, float* pred, float* hidden, void* ws, size_t ws_bytes,
                               regt_stream_t st, bool xp_is_bf16 = false) {
     TRY(check_dims(dims));
+    CallScope call(dims);
     REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && (graph->node_region || graph->overlap), "regt_forward: graph incomplete");
     TRY(check_ptrs(params, *dims));
     REGT_CHECK_ARG((x || xp_ext) && pred && hidden && ws, "regt_forward: NULL pointer");
@@ -1124,6 +1186,7 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
                       const float* dpred, const float* dhidden, const float* hidden, const float* x_packed, void* ws,
                       size_t ws_bytes, regt_stream_t st) {
     TRY(check_dims(dims));
+    CallScope call(dims);
     REGT_CHECK_ARG(graph && graph->rowptr && (graph->node_region || graph->overlap), "regt_backward: graph incomplete");
     TRY(check_ptrs(params, *dims));
     REGT_CHECK_ARG(grads && dpred && hidden && ws, "regt_backward: NULL pointer");
@@ -1139,7 +1202,7 @@ int32_t regt_backward(const regt_dims* dims, const regt_graph* graph, const regt
     hipStream_t hs = (hipStream_t)st;
     const int qbf = q_format(ws);
     REGT_CHECK_ARG((qbf & FMT_QBF) == (bf16_intermediates(*dims) ? 1 : 0),
-                   "regt_backward: the GEMM arithmetic changed since the forward on this workspace (regt_set_gemm_mode between forward and backward)");
+                   "regt_backward: the GEMM arithmetic changed since the forward on this workspace (another regt_dims.arith, or regt_set_gemm_mode between forward and backward)");
     REGT_CHECK_ARG(!(qbf & FMT_XCALLER) || x_packed, "regt_backward: the forward ran on the caller's bf16 packed input; pass the same buffer as x_packed");
     if (!graphs_wanted((long)dims->N * dims->T))
         return backward_impl(*dims, *graph, *params, *grads, dpred, dhidden, hidden, x_packed, L, hs, qbf);
@@ -1167,6 +1230,7 @@ int32_t regt_graph_stats(int64_t* out) {
 int32_t regt_cell_forward(const regt_dims* dims, const regt_graph* graph, const regt_params* params, const float* x,
                           const float* h_in, float* pred, float* hidden, void* ws, size_t ws_bytes, regt_stream_t st) {
     TRY(check_dims(dims));
+    CallScope call(dims);
     REGT_CHECK_ARG(dims->regional == 0, "regt_cell_forward: dims.regional must be 0");
     REGT_CHECK_ARG(graph && graph->rowptr && graph->col && graph->val && !graph->overlap, "regt_cell_forward: graph incomplete");
     TRY(check_ptrs(params, *dims, true));
@@ -1182,6 +1246,7 @@ int32_t regt_cell_backward(const regt_dims* dims, const regt_graph* graph, const
                            const float* dpred, const float* dhidden, const float* hidden, const float* h_in, float* dh_in,
                            void* ws, size_t ws_bytes, regt_stream_t st) {
     TRY(check_dims(dims));
+    CallScope call(dims);
     REGT_CHECK_ARG(dims->regional == 0, "regt_cell_backward: dims.regional must be 0");
     REGT_CHECK_ARG(graph && graph->rowptr && !graph->overlap, "regt_cell_backward: graph incomplete");
     TRY(check_ptrs(params, *dims, true));
@@ -1258,6 +1323,7 @@ size_t regt_cell0_workspace_bytes(const regt_dims* dims, int32_t kz, int32_t kh)
 int32_t regt_cell0_forward(const regt_dims* dims, const regt_cell0_args* args, float* pred, float* hidden, void* ws, size_t ws_bytes,
                            regt_stream_t st_) {
     TRY(check_cell0(dims, args));
+    CallScope call(dims);
     REGT_CHECK_ARG(pred && hidden && ws && al16(hidden) && al16(ws), "regt_cell0_forward: NULL / unaligned pointer");
     const regt_dims& d = *dims;
     const regt_cell0_args& a = *args;
@@ -1285,6 +1351,7 @@ int32_t regt_cell0_forward(const regt_dims* dims, const regt_cell0_args* args, f
 int32_t regt_cell0_backward(const regt_dims* dims, const regt_cell0_args* args, const regt_cell0_grads* grads, const float* dpred,
                             const float* dhidden, const float* hidden, void* ws, size_t ws_bytes, regt_stream_t st_) {
     TRY(check_cell0(dims, args));
+    CallScope call(dims);
     REGT_CHECK_ARG(grads && dpred && hidden && ws, "regt_cell0_backward: NULL pointer");
     const regt_cell0_grads& g = *grads;
     REGT_CHECK_ARG(g.gz && g.gh && g.cz && g.ch && g.head1_w && g.head1_b && g.head2_w && g.head2_b,

@@ -798,7 +798,12 @@ __global__ __launch_bounds__(256, 4) void gemm_flat_small_kernel(GemmSegs S, lon
 // (gemm_split.h) for the GEMMs whose B operand is stored [N][K].  2: plain bf16 operands (one product), fp32 accumulate --
 // reduced precision, the arithmetic BASELINE configs[4] names.
 static int g_gemm_mode = -1;
+// per-call override (regt_dims.arith, set for the duration of one entry point on the calling thread by CallScope): two models of
+// one process can run different arithmetics without touching the process default
+static thread_local int t_gemm_mode = -1;
+int gemm_mode_override(int mode) { const int prev = t_gemm_mode; t_gemm_mode = mode; return prev; }
 int gemm_mode() {
+    if (t_gemm_mode >= 0) return t_gemm_mode;
     if (g_gemm_mode < 0) {
         const char* e = getenv("REGT_GEMM_MODE");
         g_gemm_mode = 0;

@@ -266,6 +266,7 @@ int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, 
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)
 int gemm_mode();
 void set_gemm_mode(int mode);
+int gemm_mode_override(int mode);   // thread-local override for one call (-1 = none); returns the previous override
 bool fp32_core_wide();   // REGT_FP32_CORE=wide (A/B timing of the two fp32 GEMM cores)
 
 // fp32 -> bf16 (round to nearest even) copies of up to 8 weight blocks in MFMA fragment order (SEG_B_FRAG), one launch:

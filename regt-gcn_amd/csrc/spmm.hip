@@ -142,21 +142,30 @@ int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_
     return REGT_OK;
 }
 // n8 groups of 8 fp32 -> 8 bf16 (packed rows handed over as fp32 by a caller of regt_forward_packed)
+template <bool NTL>
 __global__ void cvt_rows_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long n8) {
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n8; o += (long)gridDim.x * blockDim.x) {
-        // read once: non-temporal, so that the fp32 rows do not displace the bf16 rows (read next by the aggregation) from the Infinity Cache
-        const float* s = reinterpret_cast<const float*>(src + 2 * o);
-        float a[8];
+        if (NTL) {
+            // read once: non-temporal, so that the fp32 rows do not displace the bf16 rows (read next by the aggregation) from the Infinity Cache
+            const float* s = reinterpret_cast<const float*>(src + 2 * o);
+            float a[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = __builtin_nontemporal_load(s + i);
-        dst[o] = make_uint4(pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7]));
+            for (int i = 0; i < 8; ++i) a[i] = __builtin_nontemporal_load(s + i);
+            dst[o] = make_uint4(pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7]));
+        } else {
+            const float4 a = src[2 * o], b = src[2 * o + 1];
+            dst[o] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
+        }
     }
 }
 int launch_cvt_rows_bf16(const float* src, void* dst, long n, hipStream_t st) {
     REGT_CHECK_ARG(n % 8 == 0, "cvt_rows_bf16: element count must be a multiple of 8");
     int blocks = cdiv(n / 8, 256);
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
+    static int ntl = -1;
+    if (ntl < 0) { const char* e = getenv("REGT_CVT_NT"); ntl = e ? atoi(e) : 1; }
+    if (ntl) hipLaunchKernelGGL(cvt_rows_bf16_kernel<true>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
+    else hipLaunchKernelGGL(cvt_rows_bf16_kernel<false>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

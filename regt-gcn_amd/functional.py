@@ -60,19 +60,24 @@ def _stream():
 class _WorkspacePool:
     """The forward leaves its activations in a multi-GB workspace that the backward reads.  Blocks are recycled
     here (keyed by device and size) instead of going back to the allocator after every step: a step then never
-    depends on allocator behaviour for its one large buffer, and two forwards in flight simply use two blocks."""
+    depends on allocator behaviour for its one large buffer, and two forwards in flight simply use two blocks.  Blocks are
+    keyed by the launch stream as well (like the caching allocator's own free lists): work enqueued on another stream may still be
+    using a block that the host has already released."""
 
     def __init__(self):
         self._free = {}
+        self._stream_of = {}
 
     def acquire(self, nbytes: int, device) -> torch.Tensor:
-        lst = self._free.get((device, nbytes))
-        if lst:
-            return lst.pop()
-        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        stream = _stream()
+        lst = self._free.get((device, stream, nbytes))
+        ws = lst.pop() if lst else torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._stream_of[ws.data_ptr()] = stream
+        return ws
 
     def release(self, ws: torch.Tensor):
-        lst = self._free.setdefault((ws.device, ws.numel()), [])
+        stream = self._stream_of.pop(ws.data_ptr(), None)
+        lst = self._free.setdefault((ws.device, stream, ws.numel()), [])
         if len(lst) < 2:
             lst.append(ws)
 
@@ -131,10 +136,15 @@ class RegTGCNFunction(torch.autograd.Function):
     """(x, *params) -> (pred (N,O), hidden (N,C)); whole-model forward and backward in HIP."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, graph: PreparedGraph, regional: bool, slope: float, packed: bool,
+    def forward(ctx, x: torch.Tensor, graph: PreparedGraph, regional: bool, slope: float, packed,
                 *params: torch.Tensor):
         """``packed`` False: x is the reference's (N,F,T) snapshot.  True: x is the extended packed input
-        (x_rows >= N, T, F) of the region-sharded path (own rows first, halo rows after; see dist.py)."""
+        (x_rows >= N, T, F) of the region-sharded path (own rows first, halo rows after; see dist.py).
+        ``packed`` may also be a tuple ``(packed, arith, flags)``: the per-call GEMM arithmetic (``_lib.ARITH_*``) and
+        ``_lib.DIMS_*`` switches of regt_dims (0, 0 = the process defaults)."""
+        arith = flags = 0
+        if isinstance(packed, tuple):
+            packed, arith, flags = packed
         lib = _lib.load()
         if not x.is_cuda:
             raise _lib.RegtError("RegT-GCN forward needs CUDA/HIP tensors: there is no CPU path in this package")
@@ -174,7 +184,7 @@ class RegTGCNFunction(torch.autograd.Function):
                 raise ValueError(f"x has {N} nodes but the prepared graph has {graph.num_nodes}")
         # shape validation, the dims / parameter-pointer structs and the workspace size only depend on (shapes, parameter
         # addresses): remembered per graph, so a steady-state step skips ~60 us of Python (TPIMS-scale steps are host-bound)
-        plan_key = (N, T, F, x_rows, regional, float(slope), tuple((p_.data_ptr(), tuple(p_.shape)) for p_ in params))
+        plan_key = (N, T, F, x_rows, regional, float(slope), arith, flags, tuple((p_.data_ptr(), tuple(p_.shape)) for p_ in params))
         plans = graph.__dict__.setdefault("_plan_cache", {})
         plan = plans.get(plan_key)
         if plan is None:
@@ -193,7 +203,7 @@ class RegTGCNFunction(torch.autograd.Function):
             for k, shp in expect.items():
                 if tuple(tens[k].shape) != shp:
                     raise ValueError(f"parameter {k} has shape {tuple(tens[k].shape)}, expected {shp}")
-            dims = _lib.Dims(N, T, F, Cdim, R, O, H1, 1 if regional else 0, float(slope))
+            dims = _lib.Dims(N, T, F, Cdim, R, O, H1, 1 if regional else 0, float(slope), int(arith), int(flags))
             gs = _graph_struct(graph, T)
             wsb = lib.regt_workspace_bytes(C.byref(dims), gs.n_chunks, gs.overlap)
             if wsb == 0:
@@ -303,6 +313,7 @@ class FusedTrainStep:
 
     def __init__(self, model, graph: PreparedGraph, num_features: int, periods: int, slope: float = 0.01):
         lib = _lib.load()
+        arith = _lib.arith_code(getattr(model, "arithmetic", None))
         self.lib, self.graph, self.regional = lib, graph, bool(model.regional)
         names = param_names(self.regional)
         named = dict(model.named_parameters())
@@ -315,7 +326,7 @@ class FusedTrainStep:
         N, F, T = graph.num_nodes, num_features, periods
         Cdim = tens["tgnn.conv.bias"].numel()
         O, H1 = tens["linear2.weight"].shape[0], tens["linear1.weight"].shape[0]
-        self.dims = _lib.Dims(N, T, F, Cdim, graph.num_regions, O, H1, 1 if self.regional else 0, float(slope))
+        self.dims = _lib.Dims(N, T, F, Cdim, graph.num_regions, O, H1, 1 if self.regional else 0, float(slope), arith, 0)
         self.gs = _graph_struct(graph, T)
         self.wsb = lib.regt_workspace_bytes(C.byref(self.dims), self.gs.n_chunks, self.gs.overlap)
         if self.wsb == 0:

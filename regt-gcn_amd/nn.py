@@ -203,8 +203,15 @@ class _FusedModel(nn.Module):
             mod = mod._modules[part]
         return mod, leaf
 
+    # GEMM arithmetic of THIS model's calls (regt_dims.arith): None = the process default (regt_set_gemm_mode / REGT_GEMM_MODE),
+    # "fp32", "bf16x3" (exact split) or "bf16" (reduced precision, BASELINE configs[4]).  Per call, no process state: two models
+    # of one process may differ.
+    arithmetic = None
+
     def _run(self, x: torch.Tensor, graph: PreparedGraph, packed: bool = False):
-        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, packed, *self._params_in_order())
+        arith = _lib.arith_code(self.arithmetic)
+        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, (packed, arith, 0) if arith else packed,
+                                     *self._params_in_order())
 
     def forward_packed(self, x_packed_ext: torch.Tensor, graph: PreparedGraph):
         """Region-sharded entry: ``x_packed_ext`` (x_rows, T, F) = own packed rows + gathered halo rows (dist.py)."""

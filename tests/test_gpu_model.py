@@ -578,3 +578,92 @@ def test_training_steps_are_bit_reproducible_with_the_side_stream(mode, f):
                     assert torch.equal(a_, b_), (it, k)
     finally:
         lib.regt_set_gemm_mode(prev)
+
+
+def _one_step(R, mod, graph, xs, y):
+    mod.zero_grad(set_to_none=True)
+    pred, hidden = mod.forward_prepared(xs, graph)
+    R.functional.mse_loss(pred, y).backward()
+    return [pred.detach().clone(), hidden.detach().clone()] + [q.grad.clone() for q in mod.parameters() if q.grad is not None]
+
+
+def test_arithmetic_is_per_call_two_models_of_one_process():
+    """regt_dims.arith (ABI v6; `model.arithmetic` on the modules): a bf16 model and an fp32 model of the same process, their calls
+    interleaved, give bit for bit what each gives alone under the process-wide switch -- and never touch that switch."""
+    import regtgcn_amd as R
+    lib = R.load_library()
+    n, e, regions, f, t, o = 3000, 24000, 8, 64, 12, 1
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=4)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(3)).cuda()
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=5)
+
+    def fresh(arith=None):
+        m = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        m.load_state_dict(p, strict=True)
+        m.arithmetic = arith
+        return m.cuda()
+
+    ref = {}
+    base = fresh()
+    graph = base.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    xs = x.cuda()
+    for mode in (0, 2):                                # what the process-wide switch gives
+        prev = lib.regt_set_gemm_mode(mode)
+        try:
+            ref[mode] = _one_step(R, base, graph, xs, y)
+        finally:
+            lib.regt_set_gemm_mode(prev)
+    assert not torch.equal(ref[0][1], ref[2][1])       # the two arithmetics do differ
+    before = lib.regt_set_gemm_mode(0)
+    lib.regt_set_gemm_mode(before)
+    m_bf, m_fp = fresh("bf16"), fresh("fp32")
+    for _ in range(2):
+        pb, hb = m_bf.forward_prepared(xs, graph)      # forward bf16, forward fp32, backward bf16, backward fp32
+        pf, hf = m_fp.forward_prepared(xs, graph)
+        m_bf.zero_grad(set_to_none=True); m_fp.zero_grad(set_to_none=True)
+        R.functional.mse_loss(pb, y).backward()
+        R.functional.mse_loss(pf, y).backward()
+        got_b = [pb.detach(), hb.detach()] + [q.grad for q in m_bf.parameters() if q.grad is not None]
+        got_f = [pf.detach(), hf.detach()] + [q.grad for q in m_fp.parameters() if q.grad is not None]
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(got_b, ref[2])) and len(got_b) == len(ref[2])
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(got_f, ref[0])) and len(got_f) == len(ref[0])
+    now = lib.regt_set_gemm_mode(before)
+    assert now == before                               # process default untouched
+    with pytest.raises(ValueError):
+        fresh("fp8").forward_prepared(xs, graph)
+
+
+def test_two_launch_streams_have_side_streams_of_their_own():
+    """Two models driven from two torch streams, steps interleaved on the host: each launch stream forks / joins a side stream of its
+    own (api.hip: one per (device, stream)), so both reproduce their single-stream results bit for bit."""
+    import regtgcn_amd as R
+    R.load_library()
+    n, e, regions, f, t, o = 4000, 30000, 8, 32, 12, 1
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=14)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(2)).cuda()
+    mods, graphs = [], []
+    for seed in (6, 7):
+        p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=seed)
+        m = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        m.load_state_dict(p, strict=True)
+        m = m.cuda()
+        mods.append(m)
+        graphs.append(m.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw]))
+    xs = x.cuda()
+    want = [_one_step(R, m, g, xs, y) for m, g in zip(mods, graphs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(5):
+        got = [None, None]
+        preds = [None, None]
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                mods[k].zero_grad(set_to_none=True)
+                preds[k] = mods[k].forward_prepared(xs, graphs[k])
+        for k in (1, 0):
+            with torch.cuda.stream(streams[k]):
+                R.functional.mse_loss(preds[k][0], y).backward()
+        torch.cuda.synchronize()
+        for k in (0, 1):
+            got[k] = [preds[k][0].detach(), preds[k][1].detach()] + [q.grad for q in mods[k].parameters() if q.grad is not None]
+            assert len(got[k]) == len(want[k]) and all(torch.equal(a_, b_) for a_, b_ in zip(got[k], want[k])), k
