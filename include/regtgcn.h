@@ -119,7 +119,7 @@ int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, 
 /* ------------------------------------------------------------------------------------------------
  * Whole-model forward / backward.
  *
- * regt_dims:  N nodes, T periods, F node features, C hidden (256 in the reference), R regions,
+ * regt_dims:  N nodes, T periods (<= 255), F node features, C hidden (256 in the reference), R regions,
  *             O output_dim, H1 head hidden (128);  regional = 1 for RegionalTemporalGCN
  *             (models/RegionalTemporalGCN.py:9-149), 0 for TemporalGCN / A3TGCN (models/TemporalGCN.py:7-91).
  * regt_graph: stacked CSR with 2N rows -- rows [0,N) = A_hat of the full graph, rows [N,2N) = the
@@ -128,6 +128,12 @@ int32_t regt_wgrad(const float* dOut, int64_t ldd, const float* A, int64_t lda, 
  *             (node*T + t) rows that lie inside one region, chunk_region (n_chunks) their region.
  * regt_params: the reference's state_dict tensors (names in comments), read-only.
  * regt_grads:  same tensors, written (not accumulated) by regt_backward; NULL entries are skipped.
+ *
+ * Reproducibility: for T <= 64 (the reference uses 6 and 12) two calls on the same inputs give bit-identical outputs and
+ * gradients -- every sum has a fixed order, and an element of the hidden state receives at most two atomically added
+ * partial sums (two addends commute).  For 64 < T <= 255 a node spans three or more 64-row blocks of the candidate
+ * kernel, its hidden state is the sum of three or more float atomics in arrival order, and results can differ in the last
+ * bits from run to run (parity within 1e-5 still holds; tests/test_gpu_model.py runs T = 150).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct regt_dims {
     int32_t N, T, F, C, R, O, H1;
@@ -308,8 +314,9 @@ int32_t regt_set_gemm_mode(int32_t mode);
 
 /* Developer switches (A/B timing and the bit-for-bit comparisons of tests/test_gpu_fused.py); returns the previous value, -1 for
  * an unknown name.  "xbf" (default 1): under REGT_GEMM_MODE=bf16, bf16 rows of x / A_hat x / L~ x and the fused forward kernel
- * where the shape allows; 0 = the three-launch forward on fp32 rows.  "spmm_rows" (default 1): the row-block aggregation
- * kernel (CSR entries of a workgroup's rows held in LDS); 0 = the column-panel kernels. */
+ * where the shape allows; 0 = the three-launch forward on fp32 rows.  "fused_bwd" (default 1): the three data-gradient launches of that
+ * arithmetic as one kernel.  "spmm_rows" (default 0 -- opt-in, measured slower): the row-block aggregation kernel (CSR entries of a
+ * workgroup's rows held in LDS) instead of the column-panel kernels.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
 int32_t regt_set_option(const char* name, int32_t value);
 
 /* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row

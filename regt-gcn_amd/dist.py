@@ -276,12 +276,18 @@ def build_shard(edge_index: torch.Tensor, region_index: Sequence[torch.Tensor], 
     """GPU graph preparation for one rank.  ``edge_index`` etc. are the GLOBAL graph (host tensors);
     ``region_owner[r]`` is the rank that owns region r (its nodes lie inside that rank's range).
 
-    ``method`` "own_rows" (default whenever the process group has ``world`` ranks): every rank normalises only the edges into
-    its own nodes and the ranks exchange degrees and need lists (:func:`_own_rows_operator`).  "global": the rank walks and
+    ``method`` "own_rows" (default whenever the process group has ``world`` ranks and the GCN operator has unit weights): every
+    rank normalises only the edges into its own nodes and the ranks exchange degrees and need lists
+    (:func:`_own_rows_operator`).  It issues COLLECTIVES (an all-gather + all-to-all of the need lists, one all-reduce of the
+    degree vector): every rank of ``group`` must call build_shard, or the job deadlocks.  With a weighted GCN operator
+    (``gcn_weight`` given -- not the RegT-GCN path, which normalises with unit weights) the rescaled halo entries
+    ``(1 * w * d_i) * d_j`` round differently in the last bit from the global build's ``(d_j * w) * d_i``; the default is
+    therefore "global" there, so that a sharded run stays bit-identical to the single-GPU operator.  "global": the rank walks and
     normalises the whole edge list by itself -- the form a single process needs when it plays one rank of a larger job
     (``bench.py --workload cfg5shard``, tests), and the reference the own-rows form is compared with bit for bit."""
     if method is None:
-        method = os.environ.get("REGT_SHARD_BUILD") or ("own_rows" if world == 1 or (dist.is_initialized() and dist.get_world_size(group) == world) else "global")
+        grouped = world == 1 or (dist.is_initialized() and dist.get_world_size(group) == world)
+        method = os.environ.get("REGT_SHARD_BUILD") or ("own_rows" if grouped and gcn_weight is None else "global")
     if method not in ("own_rows", "global"):
         raise ValueError("build_shard: method must be 'own_rows' or 'global'")
     if method == "own_rows":
