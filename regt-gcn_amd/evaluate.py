@@ -38,6 +38,32 @@ def predict_metrics(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor
     return mae, rmse, mape
 
 
+@torch.no_grad()
+def predict_metrics_batched(model, store, graphs, snap_batch: int) -> Tuple[float, float, float]:
+    """predict_metrics() with ``snap_batch`` snapshots per forward (train.WindowStore / train.BatchedGraphs): the same three means --
+    the 95th percentile and the infinity rule stay PER SNAPSHOT, as in predict.py:141-194."""
+    model.eval()
+    ae = torch.zeros((), dtype=torch.float64, device=store.X.device)
+    se = torch.zeros_like(ae)
+    ape = torch.zeros_like(ae)
+    ape_n = torch.zeros_like(ae)
+    per = store.Y.shape[1] * store.Y.shape[2]
+    for i in range(0, len(store), snap_batch):
+        b = min(snap_batch, len(store) - i)
+        x, y = store.batch(i, b)
+        out, _ = model.forward_prepared(x, graphs.get(b))
+        d = (y - out).abs().view(b, per)
+        ae += d.sum(dtype=torch.float64)
+        se += (d * d).sum(dtype=torch.float64)
+        q = torch.quantile(y.view(b, per).double(), 0.95, dim=1, keepdim=True).to(d.dtype)
+        r = d / q
+        ok = ~torch.isinf(r).any(dim=1)
+        ape += r[ok].sum(dtype=torch.float64)
+        ape_n += ok.sum() * per
+    n = float(store.Y.numel())
+    return float(ae) / n, (float(se) / n) ** 0.5, (float(ape) / float(ape_n) * 100 if float(ape_n) else float("nan"))
+
+
 def load_processed_pickle(path: str) -> Dict[str, torch.Tensor]:
     """The reference's ``tpims_data_small.pkl``: a ``torch.save``d 13-tuple (edge_index, edge_attr, 5 x (edge_r_index,
     edge_r_attr), node_data_list) with node_data_list = per-timestep (N, 8) float64 (load_dataset.py:436-437).

@@ -311,8 +311,13 @@ class FusedTrainStep:
     The parameters' ``.grad`` become views of one flat accumulator, so any torch optimizer works; clear them with
     :meth:`zero_grad` (or ``optimizer.zero_grad(set_to_none=False)``).  Build it after ``model.to(device)``."""
 
-    def __init__(self, model, graph: PreparedGraph, num_features: int, periods: int, slope: float = 0.01):
+    def __init__(self, model, graph: PreparedGraph, num_features: int, periods: int, slope: float = 0.01,
+                 loss_count: Optional[int] = None):
+        """``loss_count``: the divisor of the squared-error sum (default: all N*O entries = the mean).  A batched graph of B
+        snapshots (prepare_graph(copies=B)) passes the entries of ONE snapshot: the loss is then the SUM of the B snapshot means
+        and the gradients are the sum run.py accumulates over those snapshots."""
         lib = _lib.load()
+        self.loss_count = loss_count
         arith = _lib.arith_code(getattr(model, "arithmetic", None))
         self.lib, self.graph, self.regional = lib, graph, bool(model.regional)
         names = param_names(self.regional)
@@ -372,7 +377,8 @@ class FusedTrainStep:
         _lib.check(lib.regt_forward(C.byref(self.dims), C.byref(self.gs), C.byref(self.ps), _lib.ptr(x), _lib.ptr(self.pred),
                                     _lib.ptr(self.hidden), _lib.ptr(self.ws), self.wsb, st), "regt_forward")
         cnt = self.pred.numel()
-        _lib.check(lib.regt_mse_loss_grad(_lib.ptr(self.pred), _lib.ptr(y), _lib.ptr(self.dpred), _lib.ptr(self.loss), cnt, cnt, st),
+        _lib.check(lib.regt_mse_loss_grad(_lib.ptr(self.pred), _lib.ptr(y), _lib.ptr(self.dpred), _lib.ptr(self.loss), cnt,
+                                          self.loss_count or cnt, st),
                    "regt_mse_loss_grad")
         _lib.check(lib.regt_backward(C.byref(self.dims), C.byref(self.gs), C.byref(self.ps), C.byref(self.gr), _lib.ptr(self.dpred),
                                      None, _lib.ptr(self.hidden), None, _lib.ptr(self.ws), self.wsb, st), "regt_backward")

@@ -317,15 +317,35 @@ def prepare_gcn_operator(edge_index: torch.Tensor, edge_weight: Optional[torch.T
     return GcnOperator(num_nodes, rp, col, val, t[0], t[1], t[2])
 
 
+def replicate_edges(edge_index: torch.Tensor, weight: Optional[torch.Tensor], copies: int, num_nodes: int):
+    """``copies`` disjoint copies of one graph: copy b holds the nodes [b*N, (b+1)*N).  Both normalisations of the path are
+    degree-local (gcn_norm, ChebConv.__norm__ with lambda_max = 2), so the operators of the replicated graph are block diagonal
+    with the single-graph operator in every block: B snapshots of the one static graph run as ONE problem of B*N nodes
+    (the per-snapshot loop of run.py:170-192 / :208-216 is additive over snapshots)."""
+    if copies == 1:
+        return edge_index, weight
+    off = (torch.arange(copies, device=edge_index.device, dtype=edge_index.dtype) * num_nodes).view(copies, 1, 1)
+    ei = (edge_index.unsqueeze(0) + off).permute(1, 0, 2).reshape(2, -1).contiguous()
+    return ei, (None if weight is None else weight.repeat(copies).contiguous())
+
+
 def prepare_graph(edge_index: torch.Tensor, gcn_weight: Optional[torch.Tensor], region_index: Sequence[torch.Tensor],
-                  region_weight: Sequence[Optional[torch.Tensor]], num_nodes: int) -> PreparedGraph:
+                  region_weight: Sequence[Optional[torch.Tensor]], num_nodes: int, copies: int = 1) -> PreparedGraph:
     """Build the stacked [A_hat; L~] operator.
+
+    ``copies`` > 1: the block-diagonal operator of ``copies`` disjoint copies of the graph (snapshot batching,
+    :func:`replicate_edges`); the result has ``copies * num_nodes`` nodes.
 
     ``gcn_weight`` is None for RegT-GCN (the cell is called with edge_weight=None,
     RegionalTemporalGCN.py:146-148) and the distance weights for TemporalGCN (TemporalGCN.py:89-90).
     """
     if len(region_index) != len(region_weight) or len(region_index) == 0:
         raise ValueError("need one weight tensor (or None) per regional edge_index")
+    if copies > 1:
+        edge_index, gcn_weight = replicate_edges(edge_index, gcn_weight, copies, num_nodes)
+        rep = [replicate_edges(ei, ew, copies, num_nodes) for ei, ew in zip(region_index, region_weight)]
+        region_index, region_weight = [r[0] for r in rep], [r[1] for r in rep]
+        num_nodes *= copies
     rp_a, col_a, val_a = gcn_csr(edge_index, gcn_weight, num_nodes)
     w_all = [cheb_edge_weights(ei, ew, num_nodes) for ei, ew in zip(region_index, region_weight)]
     try:

@@ -240,10 +240,11 @@ class RegionalTemporalGCN(_FusedModel):
         self._graphs = _GraphCache()
 
     def prepare_graph(self, edge_index, region_index: Sequence[torch.Tensor], region_attr: Sequence[torch.Tensor],
-                      num_nodes: Optional[int] = None) -> PreparedGraph:
-        """Normalise + sort the static graph once; pass the result to :meth:`forward_prepared`."""
+                      num_nodes: Optional[int] = None, copies: int = 1) -> PreparedGraph:
+        """Normalise + sort the static graph once; pass the result to :meth:`forward_prepared`.  ``copies`` = B builds the
+        block-diagonal graph of B snapshots (train.train_epoch_batched): forward_prepared then takes x of shape (B*N, F, T)."""
         n = self.num_nodes if num_nodes is None else num_nodes
-        return prepare_graph(edge_index, None, list(region_index), list(region_attr), n)
+        return prepare_graph(edge_index, None, list(region_index), list(region_attr), n, copies)
 
     def forward_prepared(self, x: torch.Tensor, graph: PreparedGraph):
         _need_cuda(x)
@@ -305,8 +306,8 @@ class TemporalGCN(_FusedModel):
         self.relu = nn.ReLU()
         self._graphs = _GraphCache()
 
-    def prepare_graph(self, edge_index, edge_attr, num_nodes: int) -> PreparedGraph:
-        return prepare_graph(edge_index, edge_attr, [edge_index], [edge_attr], num_nodes)
+    def prepare_graph(self, edge_index, edge_attr, num_nodes: int, copies: int = 1) -> PreparedGraph:
+        return prepare_graph(edge_index, edge_attr, [edge_index], [edge_attr], num_nodes, copies)
 
     def forward_prepared(self, x: torch.Tensor, graph: PreparedGraph):
         _need_cuda(x)

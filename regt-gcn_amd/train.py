@@ -68,6 +68,77 @@ def evaluate(model, xs, ys, graph) -> Tuple[float, float]:
     return float(m.sqrt()), float(m)
 
 
+# ---- snapshot batching ---------------------------------------------------------------------------------------------------------------
+# run.py:170-192 runs one forward / backward per snapshot and ADDS the gradients of all train snapshots; the test loop (:208-216)
+# averages squared errors over all test snapshots.  Both are additive over snapshots, and the graph is the same in every one of
+# them, so B snapshots can run as ONE problem on the block-diagonal graph of B copies (graph.replicate_edges): M = B*N*T rows per
+# launch instead of N*T.  At TPIMS size (N = 104) a per-snapshot step is ~40 dependent launches of 5-25 us -- latency, not work;
+# batching turns the same launches into work.  Gradients = the same sum (another summation order), per-snapshot losses are
+# still reported, the optimiser still steps once per epoch.
+
+class WindowStore:
+    """All sliding windows of a run, device-resident and stacked: X (S, N, F, T), Y (S, N, O) -- load_dataset.py:451-457 -- so that a
+    batch of B consecutive snapshots is a VIEW (B*N, F, T) of X, no per-step copy."""
+
+    def __init__(self, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor]):
+        self.X = torch.stack(list(xs)).contiguous() if len(xs) else torch.empty(0)
+        self.Y = torch.stack(list(ys)).contiguous() if len(ys) else torch.empty(0)
+
+    def __len__(self):
+        return self.X.shape[0]
+
+    def batch(self, i: int, b: int):
+        x, y = self.X[i:i + b], self.Y[i:i + b]
+        return x.reshape(-1, x.shape[2], x.shape[3]), y.reshape(-1, y.shape[2])
+
+
+class BatchedGraphs:
+    """prepare_graph(copies=b) per batch size b in use (the epoch's last batch may be shorter), built on first use."""
+
+    def __init__(self, build):
+        self._build, self._by_size = build, {}
+
+    def get(self, b: int):
+        if b not in self._by_size:
+            self._by_size[b] = self._build(b)
+        return self._by_size[b]
+
+
+def train_epoch_batched(model, store: WindowStore, graphs: BatchedGraphs, optimizer, snap_batch: int) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """train_epoch() with ``snap_batch`` snapshots per forward / backward; returns (last snapshot's loss, all per-snapshot losses)."""
+    model.train()
+    losses = []
+    n_o = store.Y.shape[1] * store.Y.shape[2]                 # entries of ONE snapshot: the divisor of run.py:180's mean
+    prev = F_.set_grad_accumulation_in_backward(True)
+    try:
+        for i in range(0, len(store), snap_batch):
+            b = min(snap_batch, len(store) - i)
+            x, y = store.batch(i, b)
+            out, _ = model.forward_prepared(x, graphs.get(b))
+            F_.mse_loss(out, y, n_o).backward()               # = the sum of the b snapshot means: gradients add up as in run.py
+            losses.append(((out.detach() - y) ** 2).view(b, -1).mean(dim=1))
+    finally:
+        F_.set_grad_accumulation_in_backward(prev)
+    allreduce_gradients(list(model.parameters()))
+    optimizer.step()
+    optimizer.zero_grad()
+    all_l = torch.cat(losses)
+    return all_l[-1], list(all_l.unbind(0))
+
+
+@torch.no_grad()
+def evaluate_batched(model, store: WindowStore, graphs: BatchedGraphs, snap_batch: int) -> Tuple[float, float]:
+    """run.py::test() with ``snap_batch`` snapshots per forward: (rmse, mse)."""
+    model.eval()
+    se = torch.zeros((), dtype=torch.float64, device=store.X.device)
+    for i in range(0, len(store), snap_batch):
+        b = min(snap_batch, len(store) - i)
+        x, y = store.batch(i, b)
+        se += ((model.forward_prepared(x, graphs.get(b))[0] - y) ** 2).sum(dtype=torch.float64)
+    m = float(se) / float(store.Y.numel())
+    return m ** 0.5, m
+
+
 def train_epoch_sharded(model, xs: Sequence[torch.Tensor], ys: Sequence[torch.Tensor], shard: Shard, pipe: HaloPipeline,
                         optimizer, global_nodes: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """train_epoch() for one region shard of a multi-GPU run: ``xs[i]`` (n_local, F, T) / ``ys[i]`` (n_local, O) are this
@@ -158,6 +229,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--max_steps", type=int, default=None, help="with --dataset_root: use the first MAX_STEPS timesteps")
     ap.add_argument("--out_dir", default="pretrained")
     ap.add_argument("--fused_step", action="store_true", help="train through functional.FusedTrainStep (no autograd; faster on small graphs)")
+    ap.add_argument("--snap_batch", type=int, default=1,
+                    help="snapshots per forward / backward (block-diagonal graph of B copies; same accumulated gradients and metrics, "
+                         "run.py:170-192 / 208-216 are additive over snapshots).  1 = one launch sequence per snapshot, as run.py")
     return ap
 
 
@@ -229,6 +303,17 @@ def main(argv=None):
         import datetime
         os.makedirs("logs", exist_ok=True)
         log = open(os.path.join("logs", datetime.datetime.now().strftime("%y-%m-%d_%H-%M") + ".txt"), "a")
+    batched = None
+    if a.snap_batch > 1:
+        if a.model not in ("RegionalTemporalGCN", "RandomTemporalGCN", "TemporalGCN"):
+            raise SystemExit("--snap_batch covers RegionalTemporalGCN / RandomTemporalGCN / TemporalGCN")
+        if a.fused_step:
+            raise SystemExit("--snap_batch and --fused_step are alternatives (both remove per-snapshot host work)")
+        if a.model == "TemporalGCN":
+            graphs = BatchedGraphs(lambda b: model.prepare_graph(ei, ea, n, copies=b))
+        else:
+            graphs = BatchedGraphs(lambda b: model.prepare_graph(ei, r_idx, r_att, copies=b))
+        batched = (WindowStore(tx, ty), WindowStore(vx, vy), graphs)
     stepper = None
     if a.fused_step:
         if a.model not in ("RegionalTemporalGCN", "RandomTemporalGCN", "TemporalGCN") or getattr(graph, "overlap", False):
@@ -236,8 +321,12 @@ def main(argv=None):
         from .functional import FusedTrainStep
         stepper = FusedTrainStep(model, graph, f, a.num_timesteps_in)
     for epoch in range(a.epochs + 1):
-        last, _ = train_epoch(model, tx, ty, graph, opt, stepper)
-        rmse, mse = evaluate(model, vx, vy, graph)
+        if batched:
+            last, _ = train_epoch_batched(model, batched[0], batched[2], opt, a.snap_batch)
+            rmse, mse = evaluate_batched(model, batched[1], batched[2], a.snap_batch)
+        else:
+            last, _ = train_epoch(model, tx, ty, graph, opt, stepper)
+            rmse, mse = evaluate(model, vx, vy, graph)
         line = "Train Loss: {:.4f}, Test RMSE: {:.4f}, MAE: {:.4f}".format(float(last), rmse, mse)   # run.py:236 format
         print(line)
         if log:

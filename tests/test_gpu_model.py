@@ -477,8 +477,9 @@ print("OK", list(st))
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
 
 
-@pytest.mark.parametrize("extra", ["", "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random"],
-                         ids=["reference_line", "graphsage", "gat", "random_decomposition"])
+@pytest.mark.parametrize("extra", ["", "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random",
+                                   "--snap_batch 16", "--model RandomTemporalGCN --decomp_type random --snap_batch 5"],
+                         ids=["reference_line", "graphsage", "gat", "random_decomposition", "snap_batch16", "random_snap_batch5"])
 def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra):
     """scripts/RegionalTemporalGCN.sh:1's argument string (copied as a string; --epochs cut to 1) drives the run.py counterpart on
     the TPIMS fixture: epochs + 1 iterations (run.py:230), the run.py:236 line per epoch, a checkpoint with the reference's file
@@ -667,3 +668,89 @@ def test_two_launch_streams_have_side_streams_of_their_own():
         for k in (0, 1):
             got[k] = [preds[k][0].detach(), preds[k][1].detach()] + [q.grad for q in mods[k].parameters() if q.grad is not None]
             assert len(got[k]) == len(want[k]) and all(torch.equal(a_, b_) for a_, b_ in zip(got[k], want[k])), k
+
+
+# ---- snapshot batching (train.train_epoch_batched / evaluate_batched / evaluate.predict_metrics_batched) ------------------------------
+def _tpims_model(R, tpims, t_in, t_out, seed):
+    n = tpims["node_data"].shape[0]
+    mod = R.RegionalTemporalGCN(8, n, t_in, t_out)
+    mod.load_state_dict(M.init_params("RegionalTemporalGCN", 8, t_in, t_out, num_nodes=n, seed=seed))
+    mod = mod.cuda()
+    ri, rw = region_lists(tpims)
+    ei, ric, rwc = tpims["edge_index"].cuda(), _cuda_list(ri), _cuda_list(rw)
+    graphs = R.train.BatchedGraphs(lambda b: mod.prepare_graph(ei, ric, rwc, copies=b))
+    return mod, graphs
+
+
+def test_batched_training_loop_matches_reference_trajectory(R, tpims):
+    """The golden run.py trajectory (golden_loop.npz: 3 train snapshots accumulate, one RMSprop step per epoch, (rmse, mse) test) with
+    ALL THREE train snapshots in one forward / backward on the block-diagonal graph of three copies (--snap_batch 3), and the test
+    snapshots two per forward: same losses, metrics and parameter sums within the per-snapshot loop's tolerances."""
+    g = load_npz("golden_loop.npz")
+    t_in, t_out = int(g["t_in"]), int(g["t_out"])
+    n_train, n_test, epochs = int(g["n_train"]), int(g["n_test"]), int(g["epochs"])
+    assert n_train == 3
+    mod, graphs = _tpims_model(R, tpims, t_in, t_out, int(g["seed"]))
+    xs, ys = R.data.snapshot_windows(tpims["node_data"][:, :, :t_in + t_out + n_train + n_test - 1], t_in, t_out)
+    xs, ys = _cuda_list(xs), _cuda_list(ys)
+    train, test = R.train.WindowStore(xs[:n_train], ys[:n_train]), R.train.WindowStore(xs[n_train:], ys[n_train:])
+    opt = torch.optim.RMSprop(mod.parameters(), lr=1e-3, weight_decay=1e-4)
+    names = [str(s) for s in g["names"]]
+    losses, metrics = [], []
+    for ep in range(epochs):
+        last, all_l = R.train.train_epoch_batched(mod, train, graphs, opt, 3)
+        losses += [float(v) for v in all_l]
+        assert float(last) == losses[-1] and len(all_l) == n_train
+        metrics.append(R.train.evaluate_batched(mod, test, graphs, 2))
+        named = dict(mod.named_parameters())
+        sums = [float(named[k].detach().double().sum()) for k in names]
+        np.testing.assert_allclose(sums, g["param_sums"][ep], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(losses, g["losses"], atol=1e-5)
+    np.testing.assert_allclose(np.array(metrics), g["metrics"], atol=1e-5)
+
+
+@pytest.mark.parametrize("model_name", ["RegionalTemporalGCN", "TemporalGCN"])
+def test_snapshot_batch_equals_per_snapshot_accumulation(R, tpims, model_name):
+    """B = 4 (+ a short last batch of 3) against the per-snapshot loop on 7 snapshots: per-snapshot losses, accumulated gradients
+    and the predict.py metrics.  Regional model and the weighted-GCN baseline."""
+    t_in, t_out, count = 12, 1, 7
+    n = tpims["node_data"].shape[0]
+    xs, ys = R.data.snapshot_windows(tpims["node_data"][:, :, :t_in + t_out + count - 1], t_in, t_out)
+    xs, ys = _cuda_list(xs), _cuda_list(ys)
+    ei = tpims["edge_index"].cuda()
+    if model_name == "RegionalTemporalGCN":
+        mod, graphs = _tpims_model(R, tpims, t_in, t_out, 31)
+    else:
+        ea = tpims["edge_attr"].cuda()
+        mod = R.TemporalGCN(8, t_in, t_out)
+        mod.load_state_dict(M.init_params("TemporalGCN", 8, t_in, t_out, seed=31))
+        mod = mod.cuda()
+        graphs = R.train.BatchedGraphs(lambda b: mod.prepare_graph(ei, ea, n, copies=b))
+    prev = R.functional.set_grad_accumulation_in_backward(True)
+    try:
+        want_l = []
+        for x, y in zip(xs, ys):
+            out, _ = mod.forward_prepared(x, graphs.get(1))
+            loss = R.functional.mse_loss(out, y)
+            loss.backward()
+            want_l.append(float(loss))
+        want_g = {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}
+        mod.zero_grad(set_to_none=True)
+        store = R.train.WindowStore(xs, ys)
+        got_l = []
+        for i in range(0, count, 4):
+            b = min(4, count - i)
+            x, y = store.batch(i, b)
+            out, _ = mod.forward_prepared(x, graphs.get(b))
+            R.functional.mse_loss(out, y, n * t_out).backward()
+            got_l += [float(v) for v in ((out.detach() - y) ** 2).view(b, -1).mean(dim=1)]
+    finally:
+        R.functional.set_grad_accumulation_in_backward(prev)
+    np.testing.assert_allclose(got_l, want_l, rtol=2e-5, atol=1e-7)
+    for k, w in want_g.items():
+        got = dict(mod.named_parameters())[k].grad
+        np.testing.assert_allclose(got.cpu().numpy(), w.cpu().numpy(), rtol=1e-4, atol=2e-6 * max(1.0, float(w.abs().max())), err_msg=k)
+    a = R.evaluate.predict_metrics(mod, xs, ys, graphs.get(1))
+    b_ = R.evaluate.predict_metrics_batched(mod, store, graphs, 4)
+    np.testing.assert_allclose(b_, a, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(R.train.evaluate_batched(mod, store, graphs, 4), R.train.evaluate(mod, xs, ys, graphs.get(1)), rtol=2e-5)
