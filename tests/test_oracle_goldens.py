@@ -151,3 +151,44 @@ def test_loop_golden(tpims):
         np.testing.assert_allclose(sums, g["param_sums"][ep], atol=5e-4, rtol=1e-5)
     np.testing.assert_allclose(losses, g["losses"], atol=2e-6)
     np.testing.assert_allclose(np.array(metrics), g["metrics"], atol=2e-6)
+
+
+@pytest.mark.parametrize("t_in,t_out", [(6, 1), (12, 3), (24, 12)])
+def test_window_construction_matches_the_reference_get(tpims, t_in, t_out):
+    """golden_windows.npz was written by the reference's own TruckParkingDataset2.get() (load_dataset.py:442-471, run under a
+    StaticGraphTemporalSignal stand-in: oracle/make_window_golden.py) on the fixture's node data: the package's window builder
+    (data.snapshot_windows, what train.py / evaluate.py feed the model), the oracle's (loop.make_windows) and the stacked
+    device-side store of the batched loop (train.WindowStore) reproduce every window -- count, three whole windows, and two
+    checksums per window over all of them -- exactly (windows are slices: no arithmetic)."""
+    import regtgcn_amd as R
+    g = load_npz("golden_windows.npz")
+    tag = f"in{t_in}_out{t_out}"
+    count, pick = int(g[f"{tag}_count"]), [int(i) for i in g[f"{tag}_pick"]]
+
+    def sums(arrs):
+        out = np.zeros((len(arrs), 2))
+        for i, a in enumerate(arrs):
+            a = a.double().numpy()
+            w = np.arange(1, a.size + 1, dtype=np.float64).reshape(a.shape)
+            out[i] = (a.sum(), (a * w).sum() / a.size)
+        return out
+
+    for name, (xs, ys) in (("data.snapshot_windows", R.data.snapshot_windows(tpims["node_data"], t_in, t_out)),
+                           ("oracle.loop.make_windows", oloop.make_windows(tpims["node_data"], t_in, t_out))):
+        assert len(xs) == len(ys) == count, name
+        for k, i in enumerate(pick):
+            assert tuple(xs[i].shape) == g[f"{tag}_features"][k].shape, name
+            assert xs[i].is_contiguous() or name.startswith("oracle")          # the package hands the kernels contiguous (N,F,T) snapshots
+            np.testing.assert_array_equal(xs[i].numpy(), g[f"{tag}_features"][k], err_msg=name)
+            np.testing.assert_array_equal(ys[i].numpy(), g[f"{tag}_targets"][k], err_msg=name)
+        np.testing.assert_allclose(sums(xs), g[f"{tag}_feature_sums"], rtol=1e-12, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(sums(ys), g[f"{tag}_target_sums"], rtol=1e-12, atol=1e-12, err_msg=name)
+    xs, ys = R.data.snapshot_windows(tpims["node_data"], t_in, t_out)
+    store = R.train.WindowStore(xs, ys)
+    assert len(store) == count
+    xb, yb = store.batch(pick[1], 2) if pick[1] + 2 <= count else store.batch(pick[1], 1)
+    n = tpims["node_data"].shape[0]
+    np.testing.assert_array_equal(xb[:n].numpy(), g[f"{tag}_features"][1])          # a batch is B windows stacked along the nodes
+    np.testing.assert_array_equal(yb[:n].numpy(), g[f"{tag}_targets"][1])
+    if xb.shape[0] == 2 * n:
+        np.testing.assert_array_equal(xb[n:].numpy(), xs[pick[1] + 1].numpy())
