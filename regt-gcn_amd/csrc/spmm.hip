@@ -132,8 +132,44 @@ __global__ void pack_x_bf16_kernel(const float* __restrict__ x, uint4* __restric
         xp[o] = v;
     }
 }
+// LDS-staged form of the same (see pack_x_lds_kernel): coalesced non-temporal 16-byte reads of whole nodes, 16-byte bf16 pieces out
+__global__ __launch_bounds__(256) void pack_x_bf16_lds_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int N, int F, int T, int NB) {
+    __shared__ float4 tile4[PACK_LDS_FLOATS / 4];
+    const float* tile = reinterpret_cast<const float*>(tile4);
+    const int FT = F * T, F8 = F / 8;
+    for (long n0 = (long)blockIdx.x * NB; n0 < N; n0 += (long)gridDim.x * NB) {
+        const int nb = N - n0 < NB ? (int)(N - n0) : NB;
+        const int tot4 = nb * FT / 4, tot8 = nb * FT / 8;
+        const float4* src = reinterpret_cast<const float4*>(x + n0 * FT);
+        for (int i = threadIdx.x; i < tot4; i += 256) {
+            const float* s = reinterpret_cast<const float*>(src + i);
+            tile4[i] = make_float4(__builtin_nontemporal_load(s), __builtin_nontemporal_load(s + 1), __builtin_nontemporal_load(s + 2),
+                                   __builtin_nontemporal_load(s + 3));
+        }
+        __syncthreads();
+        uint4* dst = xp + n0 * (FT / 8);
+        for (int o = threadIdx.x; o < tot8; o += 256) {  // o = (node, t, f8)
+            const int n = o / (T * F8), rem = o - n * T * F8;
+            const int t = rem / F8, f = (rem - t * F8) * 8;
+            const float* b = tile + n * FT + f * T + t;
+            dst[o] = make_uint4(pk2(b[0], b[T]), pk2(b[2 * T], b[3 * T]), pk2(b[4 * T], b[5 * T]), pk2(b[6 * T], b[7 * T]));
+        }
+        __syncthreads();
+    }
+}
 int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_t st) {
     REGT_CHECK_ARG(F % 8 == 0, "pack_x (bf16 rows): F = %d must be a multiple of 8", F);
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("REGT_PACK"); variant = e ? atoi(e) : 3; }
+    const int FT = F * T;
+    if (variant >= 2 && FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
+        const int NB = PACK_LDS_FLOATS / FT;
+        long blocks = cdiv((long)N, NB);
+        if (blocks > 256L * 16) blocks = 256L * 16;
+        hipLaunchKernelGGL(pack_x_bf16_lds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, reinterpret_cast<uint4*>(xp), N, F, T, NB);
+        REGT_CHECK_LAUNCH();
+        return REGT_OK;
+    }
     const long total = (long)N * T * (F / 8);
     int blocks = cdiv(total, 256);
     if (blocks > 16384) blocks = 16384;
