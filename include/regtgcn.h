@@ -316,7 +316,9 @@ int32_t regt_set_gemm_mode(int32_t mode);
  * an unknown name.  "xbf" (default 1): under REGT_GEMM_MODE=bf16, bf16 rows of x / A_hat x / L~ x and the fused forward kernel
  * where the shape allows; 0 = the three-launch forward on fp32 rows.  "fused_bwd" (default 1): the three data-gradient launches of that
  * arithmetic as one kernel.  "spmm_rows" (default 0 -- opt-in, measured slower): the row-block aggregation kernel (CSR entries of a
- * workgroup's rows held in LDS) instead of the column-panel kernels.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
+ * workgroup's rows held in LDS) instead of the column-panel kernels.  "dgrad1_gen" (default 1): fp32 arithmetic, the candidate data gradient
+ * forms its left operand dhp from Z, H~, dOH while staging it and its epilogue writes dzp and the attention dots (no separate
+ * cell-backward pass); 0 = the two launches.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
 int32_t regt_set_option(const char* name, int32_t value);
 
 /* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row

@@ -306,7 +306,9 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.cb_npb = (L.cb_npb + 3) / 4 * 4;
     L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
     L.dp_partial = take((long)L.cb_blocks * T);
-    L.rowdot = take(M);                               // per-row <dOH, H'> of the fused backward kernel (fused.hip)
+    // per-row <dOH, H'>: one float per row (fused backward kernel, fused.hip) or one partial dot per 128-column tile of the row
+    // (fp32 candidate data gradient with a generated left operand, gemm_dgrad1_gen_kernel)
+    L.rowdot = take(M * (C / 128 > 1 ? C / 128 : 1));
     // one slab region per weight gradient (their reductions are deferred into one launch, ReduceQueue): the sum of
     // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
     long slab = (long)L.nchunks * (C * C + C) + (long)L.nchunks * (2 * C * C + 2 * C)
@@ -815,6 +817,27 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, sa));
         }
     } else {
+    // fp32 arithmetic at sizes the 128 x 128 core covers: dhp is GENERATED inside the candidate data gradient's K loop and dzp /
+    // the attention dots come out of its epilogue -- cell_bwd's pass over Z, h, H~ (5 C floats per row) does not happen
+    // (gemm_split.h: run_u_gen; REGT_DGRAD1_GEN=0 restores the two launches)
+    const bool gen = split && !ibf && !abf && gemm_dgrad1_gen_ok(M, C, N) && al16(L.Ht) && al16(L.dhp);
+    if (gen) {
+        GemmSegs S{};
+        S.nseg = 1;
+        S.seg[0] = make_seg(L.dhp, C, L.UT, nullptr, C, INT_MAX, C, true);      // (A is generated: the pointer is not read)
+        S.row_div = T;
+        EpiDgrad1 e{H, L.ZR, L.dOH, L.probs, L.dzr, DH, C, T};
+        e.Ht = L.Ht; e.dhp = L.dhp; e.rowdot = L.rowdot; e.num_nodes = N;
+        {
+            PROF("dgrad_candidate", st);
+            TRY(launch_gemm_dgrad1_gen(S, M, C, e, st));
+        }
+        if (gr.attention) {      // (tail of the attention gradient: off the critical path, joined before the slab reduction)
+            hipStream_t sa = side_fork(st);
+            TRY(launch_rowdot_reduce(L.rowdot, L.dp_partial, N, T, L.cb_npb, sa, C / 128));
+            TRY(launch_att_bwd(L.dp_partial, L.cb_blocks, L.probs, gr.attention, T, sa));
+        }
+    } else {
     // ---- cell: gate pre-activation gradients ------------------------------------------------------
     {
         CellBwdArgs a{L.dOH, L.probs, L.ZR, H, L.Ht, L.dhp, L.dzr, L.dp_partial, N, T, C, L.cb_npb};
@@ -836,6 +859,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         e.dzr_bf16 = ibf; e.h_bf16 = abf; e.zr_bf16 = abf; e.dh_bf16 = abf;
         PROF("dgrad_candidate", st);
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
+    }
     }
     {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
         GemmSegs S{};
@@ -1021,6 +1045,7 @@ int32_t regt_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
+    if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);
     set_error("regt_set_option: unknown option '%s'", name);
     return -1;
 }

@@ -165,14 +165,19 @@ int cell_bwd_blocks(int num_nodes, int nodes_per_block) { return cdiv(num_nodes,
 // nodes_per_block consecutive nodes; thread (g, t) adds rowdot[node * T + t] for the nodes n0 + g, n0 + g + G, ... (ascending),
 // thread t then adds the G group sums in order -- a fixed summation order, like cell_bwd_kernel's.
 __global__ __launch_bounds__(256) void rowdot_reduce_kernel(const float* __restrict__ rowdot, float* __restrict__ dp_partial,
-                                                            int num_nodes, int T, int nodes_per_block) {
+                                                            int num_nodes, int T, int nodes_per_block, int parts) {
     __shared__ float part[256];
     const int G = 256 / T, g = threadIdx.x / T, t = threadIdx.x - g * T;
     const int n0 = blockIdx.x * nodes_per_block;
     const int n1 = n0 + nodes_per_block < num_nodes ? n0 + nodes_per_block : num_nodes;
     float s = 0.f;
     if (g < G)
-        for (int node = n0 + g; node < n1; node += G) s += rowdot[(long)node * T + t];
+        for (int node = n0 + g; node < n1; node += G) {
+            const float* q = rowdot + ((long)node * T + t) * parts;
+            float r = q[0];
+            for (int k = 1; k < parts; ++k) r += q[k];
+            s += r;
+        }
     part[threadIdx.x] = s;
     __syncthreads();
     if ((int)threadIdx.x < T) {
@@ -181,10 +186,10 @@ __global__ __launch_bounds__(256) void rowdot_reduce_kernel(const float* __restr
         dp_partial[(long)blockIdx.x * T + threadIdx.x] = acc;
     }
 }
-int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st) {
-    REGT_CHECK_ARG(T >= 1 && T <= CB_MAXT, "rowdot_reduce: T=%d outside 1..%d", T, CB_MAXT);
+int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st, int parts) {
+    REGT_CHECK_ARG(T >= 1 && T <= CB_MAXT && parts >= 1, "rowdot_reduce: T=%d outside 1..%d", T, CB_MAXT);
     hipLaunchKernelGGL(rowdot_reduce_kernel, dim3(cell_bwd_blocks(num_nodes, nodes_per_block)), dim3(256), 0, st, rowdot, dp_partial,
-                       num_nodes, T, nodes_per_block);
+                       num_nodes, T, nodes_per_block, parts);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

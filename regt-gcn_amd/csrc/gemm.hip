@@ -285,6 +285,104 @@ struct EpiDgrad1F {
 #undef F_
     }
 };
+// EpiDgrad1F behind a GENERATED left operand (SplitCore::run_u_gen): with H~ at hand as well, the epilogue also forms
+// dzp = g (h - H~) Z (1 - Z) -> dzr[m, c] and the row's partial attention dot <dOH[node], Z h + (1 - Z) H~> over the tile's
+// 128 columns (summed over a half wave: the 32 lanes that share a row) -> rowdot[m * parts + column tile]; cell_bwd_kernel's
+// three outputs without its pass over Z, h, H~.  fp32 arrays only.
+struct EpiDgrad1GenF {
+    EpiDgrad1 e;
+    int parts;              // C / 128 column tiles
+    static constexpr int ROUND_ROWS = 8;
+    __device__ __forceinline__ static float half_wave_sum(float s) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        return s;
+    }
+    struct Aux { float4 h, Z, R, d, t; float p; };
+    __device__ __forceinline__ Aux load(long m, int c) const {
+        const long node = m / e.T;
+        Aux a;
+        a.p = e.probs[(int)(m - node * e.T)];
+        a.h = ld4(e.h + m * e.C + c);
+        a.Z = ld4(e.ZR + m * (2L * e.C) + c);
+        a.R = ld4(e.ZR + m * (2L * e.C) + e.C + c);
+        a.d = ld4(e.dOH + node * e.C + c);
+        a.t = ld4(e.Ht + m * e.C + c);
+        return a;
+    }
+#define REGT_GEN_DOT(a) ((a.d.x * (a.Z.x * a.h.x + (1.0f - a.Z.x) * a.t.x) + a.d.y * (a.Z.y * a.h.y + (1.0f - a.Z.y) * a.t.y)) + \
+                         (a.d.z * (a.Z.z * a.h.z + (1.0f - a.Z.z) * a.t.z) + a.d.w * (a.Z.w * a.h.w + (1.0f - a.Z.w) * a.t.w)))
+    __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
+#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+        st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
+#undef F_
+#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+        st4(e.dh + m * e.C + c, REGT_V4(F_));
+#undef F_
+#define F_(k) cb_dzp(__fmul_rn(a.p, a.d.k), a.h.k, a.t.k, a.Z.k)
+        st4(e.dzr + m * (2L * e.C) + c, REGT_V4(F_));
+#undef F_
+        // (guarded path of a partial tile: the 32 lanes of a row take this branch together -- rows are uniform per half wave)
+        const float s = half_wave_sum(REGT_GEN_DOT(a));
+        if ((threadIdx.x & 31) == 0) e.rowdot[m * parts + c / GBN] = s;
+    }
+    static constexpr int NVAR = 1;
+    static constexpr bool HAS_ROWTAB = true;
+    struct Col {};
+    struct Tile { __amdgpu_buffer_rsrc_t h, zr, d, dzr, dh, t, rd; int vc, vzr, sc, szr, vd, vrd, srd, rstep; const EpiRowEnt* rt; };
+    __device__ __forceinline__ int variant(int) const { return 0; }
+    __device__ __forceinline__ EpiRowEnt vrow(long m) const {
+        const long node = m / e.T;
+        return EpiRowEnt{(int)(node * e.C * 4), e.probs[(int)(m - node * e.T)]};
+    }
+    template <int V> __device__ __forceinline__ Col vcol(int) const { return Col{}; }
+    template <int V> __device__ __forceinline__ Tile vtile(const EpiGeom& g) const {
+        Tile t;
+        t.h = buf_srd(e.h + g.m0 * e.C + g.n0);
+        t.t = buf_srd(e.Ht + g.m0 * e.C + g.n0);
+        t.dh = buf_srd(e.dh + g.m0 * e.C + g.n0);
+        t.zr = buf_srd(e.ZR + g.m0 * (2L * e.C) + g.n0);
+        t.d = buf_srd(e.dOH + g.n0);
+        t.dzr = buf_srd(e.dzr + g.m0 * (2L * e.C) + g.n0);
+        t.rd = buf_srd(e.rowdot + g.m0 * parts + g.n0 / GBN);
+        t.vc = (g.rr * e.C + g.c) * 4;
+        t.sc = g.step * e.C * 4;
+        t.vzr = 2 * t.vc - g.c * 4;
+        t.szr = 2 * t.sc;
+        t.vd = g.c * 4;
+        t.vrd = g.rr * parts * 4;
+        t.srd = g.step * parts * 4;
+        t.rt = g.rowtab + g.rr;
+        t.rstep = g.step;
+        return t;
+    }
+    struct VAux { float4 h, Z, R, d, t; float p; };
+    template <int V> __device__ __forceinline__ VAux vload(const Tile& t, int i) const {
+        const EpiRowEnt re = t.rt[i * t.rstep];
+        VAux a;
+        a.p = re.p;
+        a.h = buf_ld4(t.h, t.vc, i * t.sc);
+        a.Z = buf_ld4(t.zr, t.vzr, i * t.szr);
+        a.R = buf_ld4(t.zr, t.vzr, i * t.szr + e.C * 4);
+        a.d = buf_ld4(t.d, t.vd + re.off, 0);
+        a.t = buf_ld4(t.t, t.vc, i * t.sc);
+        return a;
+    }
+    template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
+#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+        buf_st4(t.dzr, t.vzr + i * t.szr + e.C * 4, 0, REGT_V4(F_));
+#undef F_
+#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+        buf_st4(t.dh, t.vc + i * t.sc, 0, REGT_V4(F_));
+#undef F_
+#define F_(k) cb_dzp(__fmul_rn(a.p, a.d.k), a.h.k, a.t.k, a.Z.k)
+        buf_st4(t.dzr, t.vzr + i * t.szr, 0, REGT_V4(F_));
+#undef F_
+        const float s = half_wave_sum(REGT_GEN_DOT(a));
+        if ((threadIdx.x & 31) == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), t.rd, t.vrd + i * t.srd, 0, 0);
+    }
+#undef REGT_GEN_DOT
+};
 struct EpiDgrad2F {
     EpiDgrad2 e;
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
@@ -748,6 +846,29 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
     WG_TRACE_END(N, t_a, t_b);
 }
 
+// dgrad_candidate with its left operand generated on the way (SplitCore::run_u_gen + EpiDgrad1GenF): cell_bwd_kernel and the candidate
+// data gradient in one launch.  fp32 arithmetic; two workgroups per CU (three operand arrays in flight per A slot).
+__global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const long m0 = (long)(bid / tiles_n) * GBM;
+    const int n0 = (bid % tiles_n) * GBN;
+    RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
+    SplitCore<false, 0> core(S, rm, n0, N, lds, true);
+    core.fill_rowtab(epi);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const SplitCore<false, 0>::AGen g{epi.e.ZR, epi.e.Ht, epi.e.dOH, epi.e.dhp, epi.e.C, (unsigned)epi.e.num_nodes * (unsigned)epi.e.C * 4u};
+    core.run_u_gen(acc, g);
+    core.for_each_vec_halves(acc, epi);
+}
+
 // bf16-operand core + 8-column epilogue (bf16 storage of the activations): same K loop as gemm_flat_split_kernel<.., 1>
 template <class EpiF8, bool REGION>
 __global__ __launch_bounds__(256, 3) void gemm_flat_split8_kernel(GemmSegs S, long M, int N, EpiF8 epi, int uniform) {
@@ -991,6 +1112,35 @@ int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hip
     REGT_CHECK_ARG(!e.dzr_bf16, "dgrad1 gemm: bf16 storage of dzr needs the bf16-operand vector path");
     if (fast_class(S, N, vec) == 0) return launch_fast<EpiDgrad1F, false, false>(S, M, N, EpiDgrad1F{e}, 0, st);
     return launch_flat(S, M, N, EpiDgrad1F{e}, vec, st);
+}
+// REGT_DGRAD1_GEN=0: keep cell_bwd + dgrad_candidate as two launches (A/B timing; same dhp / dzp / drp / dh to the bit, the
+// attention gradient in another fixed summation order)
+static int g_dgrad1_gen = -1;
+static bool dgrad1_gen_wanted() {
+    if (g_dgrad1_gen < 0) { const char* e = getenv("REGT_DGRAD1_GEN"); g_dgrad1_gen = e ? atoi(e) : 1; }
+    return g_dgrad1_gen != 0;
+}
+int dgrad1_gen_option(int value) {       // regt_set_option("dgrad1_gen", v): returns the previous setting
+    const int prev = dgrad1_gen_wanted() ? 1 : 0;
+    g_dgrad1_gen = value ? 1 : 0;
+    return prev;
+}
+bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes) {
+    return dgrad1_gen_wanted() && gemm_mode() == 0 && !fp32_core_wide() && !gemm_desc_table_forced() && C % GBN == 0 && C % GBK == 0 &&
+           (long)cdiv(M, GBM) * (C / GBN) >= SMALL_TILE_LIMIT && M < (1L << 31) && (long)num_nodes * C * 4 < (1L << 31) &&
+           (long)C * 8 * (GBM + 1) < (1L << 31);
+}
+int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st) {
+    REGT_CHECK_ARG(N == e.C && S.nseg == 1 && S.seg[0].K == e.C && (S.seg[0].flags & SEG_BT) && (S.seg[0].flags & SEG_VEC_B) &&
+                   !(S.seg[0].flags & (SEG_A_BF16 | SEG_B_FRAG | SEG_REGION | SEG_REPEAT)), "dgrad1 (generated operand): one [N][K] weight segment with K = C");
+    REGT_CHECK_ARG(gemm_dgrad1_gen_ok(M, e.C, e.num_nodes), "dgrad1 (generated operand): shape / arithmetic not covered");
+    REGT_CHECK_ARG(e.Ht && e.dhp && e.rowdot && !e.dzr_bf16 && !e.h_bf16 && !e.zr_bf16 && !e.dh_bf16, "dgrad1 (generated operand): fp32 arrays, all outputs given");
+    REGT_CHECK_ARG(a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh) && a16(e.Ht) && a16(e.dhp), "dgrad1 (generated operand): 16-byte aligned arrays");
+    const long tiles = (long)cdiv(M, GBM) * (N / GBN);
+    REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
+    hipLaunchKernelGGL(gemm_dgrad1_gen_kernel, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN});
+    REGT_CHECK_LAUNCH();
+    return REGT_OK;
 }
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st) {
     REGT_CHECK_ARG(N == e.C, "dgrad2 gemm expects N == C");

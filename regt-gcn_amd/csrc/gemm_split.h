@@ -320,6 +320,149 @@ struct SplitCore : FastCore<true, REGION> {
         __syncthreads();
     }
 
+    // ---- GENERATED A operand (fp32 core, NP = 0): the candidate data gradient without a stored left operand ------------------
+    // dq = dhp Uh2 with dhp[m, k] = g (1 - Z)(1 - H~^2), g = p_t dOH[node]  (the transposes of models/utils.py:181-188).  Round 1-3:
+    // cell_bwd_kernel read Z, h, H~ and wrote dhp, dzp (5 C floats per row) only to hand dhp to this GEMM, which read it back.
+    // Here the A slots of a thread are FORMED from Z, H~ and dOH while they are staged -- same rows, same k-quads, same LDS image
+    // as run_u -- and the column-tile-0 workgroup of a row tile stores them to dhp on the way (the weight gradients dUh / dGh
+    // still need it); the epilogue (EpiDgrad1GenF, gemm.hip) adds dzp and the per-row attention dot, so cell_bwd disappears:
+    // 8 C floats per row instead of 11 cross HBM.  Three loads per slot instead of one: 48 instead of 16 operand VGPRs -- this
+    // kernel runs two workgroups per CU.
+    struct AGen {
+        const float* ZR; const float* Ht; const float* dOH; float* dhp;
+        int C; unsigned doh_bytes;                 // dOH is (num_nodes, C) fp32: doh_bytes = num_nodes * C * 4 (host-checked < 2^31)
+    };
+    struct GenRegs { float4 z[4], t[4], d[4]; };   // slot h + 2 j: Z, H~, dOH quads of row (tid >> 2) + 64 j, half h
+    struct GenRows { int vz[2], vh[2], vd[2]; float p[2]; };
+    struct GenSrd { __amdgpu_buffer_rsrc_t z, t, d, o; };
+    __device__ __forceinline__ GenRows gen_rows(const AGen& g) const {       // needs the row table (fill_rowtab + barrier)
+        GenRows r;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = (tid >> 2) + 64 * j;
+            const EpiRowEnt re = Base::rowtab()[rl];
+            r.p[j] = re.p;
+            r.vd[j] = re.off + (tid & 3) * 16;
+            r.vz[j] = rl * g.C * 8 + (tid & 3) * 16;
+            r.vh[j] = rl * g.C * 4 + (tid & 3) * 16;
+        }
+        return r;
+    }
+    // descriptors of the tile's rows of Z (inside [Z|R], row stride 2 C), H~, dhp and of all of dOH; dead: zero records --
+    // a load returns 0 without touching memory, a store is dropped (`writer`: only column tile 0 stores dhp)
+    __device__ __forceinline__ GenSrd gen_srd(const AGen& g, bool live, bool writer) const {
+        GenSrd s;
+        const int C = g.C;
+        s.z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.ZR + rm.base * 2L * C), 0, live ? rm.nvalid * C * 8 : 0, 0x00020000);
+        s.t = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Ht + rm.base * (long)C), 0, live ? rm.nvalid * C * 4 : 0, 0x00020000);
+        s.d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dOH), 0, live ? (int)g.doh_bytes : 0, 0x00020000);
+        s.o = __builtin_amdgcn_make_buffer_rsrc(g.dhp + rm.base * (long)C, 0, writer ? rm.nvalid * C * 4 : 0, 0x00020000);
+        return s;
+    }
+    __device__ __forceinline__ void gen_load_half(int h, const GenSrd& s, const GenRows& r, int k0, GenRegs& q) const {
+        const int so = (k0 + 16 * h) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            q.z[h + 2 * j] = buf_ld4(s.z, r.vz[j], so);
+            q.t[h + 2 * j] = buf_ld4(s.t, r.vh[j], so);
+            q.d[h + 2 * j] = buf_ld4(s.d, r.vd[j], so);
+        }
+    }
+    __device__ __forceinline__ void gen_store_half(int h, const GenSrd& s, const GenRows& r, int k0, const GenRegs& q, const float4 (&rb)[4]) const {
+        char* st = reinterpret_cast<char*>(lds) + h * STAGE_B;
+        const int ko = (k0 + 16 * h) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int off = cp_off((tid >> 2) + 64 * j, tid & 3);
+            const float4 z = q.z[h + 2 * j], t = q.t[h + 2 * j], d = q.d[h + 2 * j];
+            const float p = r.p[j];
+            float4 a;
+            a.x = cb_dhp(__fmul_rn(p, d.x), z.x, t.x); a.y = cb_dhp(__fmul_rn(p, d.y), z.y, t.y);
+            a.z = cb_dhp(__fmul_rn(p, d.z), z.z, t.z); a.w = cb_dhp(__fmul_rn(p, d.w), z.w, t.w);
+            *reinterpret_cast<float4*>(st + off) = a;
+            *reinterpret_cast<float4*>(st + OPER_B + off) = rb[h + 2 * j];
+            buf_st4(s.o, r.vh[j] + ko, 0, a);          // (row + k offset in the VECTOR offset: see the store hazard note in DESIGN 5c.3)
+        }
+    }
+    __device__ __forceinline__ void load_b_half(int h, const SrdsU& d, float4 (&rb)[4]) const {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rb[h + 2 * j] = buf_ld4(d.b, d.vb[j], d.sb + 64 * h);
+    }
+    // run_u's schedule with generated A slots; ONE segment (its B = the weights, [N][K]; its A pointer is not read), K % 32 == 0
+    __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g) {
+        static_assert(NP == 0, "generated A operand: fp32 core");
+        nreg_u = 0;
+        const int nslab = S.seg[0].K / GBK;
+        if (nslab == 0) return;
+        const bool writer = n0 == 0;
+        __syncthreads();                            // the row table (fill_rowtab) is complete
+        const GenRows rows = gen_rows(g);
+        GenRegs q;
+        float4 rb[4];
+        SegCursor c{0, 0, 0};
+        int k_held = 0;
+        {
+            const SrdsU d = make_u(c, true);
+            const GenSrd s = gen_srd(g, true, writer);
+            gen_load_half(0, s, rows, 0, q);
+            gen_load_half(1, s, rows, 0, q);
+            load_b_half(0, d, rb);
+            load_b_half(1, d, rb);
+            gen_store_half(0, s, rows, 0, q, rb);
+            gen_store_half(1, s, rows, 0, q, rb);
+        }
+        {
+            const bool two = nslab > 1;
+            if (two) cursor_next(c);
+            const SrdsU d = make_u(c, two);
+            const GenSrd s = gen_srd(g, two, writer);
+            gen_load_half(0, s, rows, GBK, q);
+            gen_load_half(1, s, rows, GBK, q);
+            load_b_half(0, d, rb);
+            load_b_half(1, d, rb);
+            k_held = GBK;
+        }
+        __syncthreads();
+        compute(0, acc);
+        const GenSrd sw = gen_srd(g, true, writer);      // for the stores of the held slab (always a live one)
+        for (int it = 0; it + 1 < nslab; ++it) {
+            const bool live = it + 2 < nslab;
+            if (live) cursor_next(c);
+            const SrdsU nx = make_u(c, live);
+            const GenSrd sn = gen_srd(g, live, writer);
+            const int k_next = (it + 2) * GBK;
+            __syncthreads();
+            fused_gen(0, 1, nx, sn, sw, rows, k_held, k_next, q, rb, acc);
+            __syncthreads();
+            fused_gen(1, 0, nx, sn, sw, rows, k_held, k_next, q, rb, acc);
+            k_held = k_next;
+        }
+        __syncthreads();
+        compute(1, acc);
+        __syncthreads();
+    }
+    __device__ __forceinline__ void fused_gen(int hs, int hc, const SrdsU& nx, const GenSrd& sn, const GenSrd& sw, const GenRows& rows,
+                                              int k_held, int k_next, GenRegs& q, float4 (&rb)[4], f32x16 (&acc)[2][2]) const {
+        __builtin_amdgcn_sched_barrier(0);
+        const Frags f = read_frags(hc);
+        gen_store_half(hs, sw, rows, k_held, q, rb);
+        mfmas(f, acc);
+        gen_load_half(hs, sn, rows, k_next, q);
+        load_b_half(hs, nx, rb);
+        // 32 MFMAs of 64 pipe cycles: the 8 fragment reads up front, then per MFMA gap a share of the generation arithmetic
+        // (~12 VALU per slot), one LDS write or dhp store, later two of the eight global loads
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);   // VALU | SALU
+            if (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        // DS write
+            else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);               // VMEM read
+            if (r >= 2 && r < 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write (dhp)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
     // fragments of half h: NP planes of two 32-row blocks per operand (4 NP x ds_read_b128)
     struct FragsB { bf16x8 a[2][NP ? NP : 1], b[2][NP ? NP : 1]; };
     // NP = 0: [32-row block][k-quad pair kk]: lane half lh holds k = 4 (2 kk + lh) .. + 3 of its row, element j feeds the

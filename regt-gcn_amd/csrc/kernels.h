@@ -87,6 +87,10 @@ struct EpiDgrad1 {      // v = dq[m, c]:  dzr[m, C+c] = v*h*R*(1-R);  dh[m, c] =
     float* dzr; float* dh; int C; int T;
     int dzr_bf16 = 0;   // dzr is stored as bf16 (row stride 2C elements)
     int h_bf16 = 0, zr_bf16 = 0, dh_bf16 = 0;
+    // launch_gemm_dgrad1_gen (fp32): the left operand dhp = g (1 - Z)(1 - H~^2) is GENERATED from Z, H~, dOH while it is staged (and
+    // stored to dhp for the weight gradients); the epilogue also writes dzp = g (h - H~) Z (1 - Z) -> dzr[m, c] and the row's
+    // partial attention dot <dOH, Z h + (1 - Z) H~> over the tile's 128 columns -> rowdot[m * (C / 128) + c / 128]
+    const float* Ht = nullptr; float* dhp = nullptr; float* rowdot = nullptr; int num_nodes = 0;
 };
 struct EpiDgrad2 {      // ds[m, c] = (dh[m, c] + v) * act'(h[m, c])   (in place on dh)
     float* dh; const float* h; int C; int act; float slope;
@@ -99,6 +103,10 @@ struct EpiMaskAdd {     // out[m, c] = v * (mask[m, c] > 0) + (add ? add[m, c] :
 int launch_gemm_bias_act(const GemmSegs& S, long M, int N, const EpiBiasAct& e, hipStream_t st);
 int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipStream_t st);
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st);
+// cell_bwd + dgrad_candidate in one launch (fp32 arithmetic, C % 128 == 0, big-tile regime): see EpiDgrad1's last fields
+bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes);
+int dgrad1_gen_option(int value);    // runtime A/B switch (regt_set_option "dgrad1_gen")
+int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st);
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st);
 int launch_gemm_mask_add(const GemmSegs& S, long M, int N, const EpiMaskAdd& e, hipStream_t st);
 
@@ -260,7 +268,8 @@ struct FusedBwdArgs {
 int launch_fused_backward(const FusedBwdArgs& a, int C, hipStream_t st);
 bool fused_backward_ok(int C);
 // dp_partial[b][t] = sum over the nodes of block b (nodes_per_block consecutive nodes, ascending) of rowdot[node * T + t]
-int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st);
+// (`parts` > 1: a row holds `parts` consecutive partial dots, added in ascending order)
+int launch_rowdot_reduce(const float* rowdot, float* dp_partial, int num_nodes, int T, int nodes_per_block, hipStream_t st, int parts = 1);
 
 // ---- cell backward head / small element-wise kernels -------------------------------------------
 // GEMM arithmetic: 0 = fp32 MFMA (default), 1 = exact 3-way bf16 split on the bf16 MFMA (gemm_split.h)

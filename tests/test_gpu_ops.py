@@ -226,3 +226,52 @@ def test_overlapping_regions_take_the_general_layout(R):
     b = torch.tensor([[2, 1], [1, 2]]).cuda()      # node 1 also receives an edge in region b
     g = R.prepare_graph(a, None, [a, b], [None, None], 3)
     assert g.overlap and g.rowptr.numel() == 3 * 3 + 1 and g.m_rowptr is None
+
+
+@pytest.mark.parametrize("n,e,regions,f,t,o,model", [(3000, 24000, 8, 32, 12, 1, "regt"), (1409, 9000, 3, 16, 12, 2, "regt"),
+                                                      (2200, 15000, 1, 8, 6, 1, "tgcn")])
+def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, t, o, model):
+    """fp32 backward with dhp generated inside the candidate data gradient (gemm_dgrad1_gen_kernel: no cell_bwd pass) against the
+    two-launch path (regt_set_option("dgrad1_gen", 0)): every gradient that flows through dhp / dzp / drp / dh is BIT-identical
+    (same element-wise helpers, same GEMM order); the attention gradient is summed in another fixed order (<= 1e-5 of its scale).
+    Full tiles, a tail tile (1409 * 12 rows), a node-boundary inside a tile, the TemporalGCN variant."""
+    import regtgcn_amd as R
+    from oracle import model as M
+    from test_gpu_model import _synthetic
+    lib = R.load_library()
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(1)).cuda()
+    if model == "regt":
+        p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    else:
+        p = M.init_params("TemporalGCN", f, t, o, seed=3)
+        mod = R.TemporalGCN(node_features=f, periods=t, output_dim=o)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        w = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(2)) * 100 + 1
+        graph = mod.prepare_graph(ei.cuda(), w.cuda(), n)
+    xs = x.cuda()
+    res = {}
+    for gen in (1, 0, 1):
+        prev = lib.regt_set_option(b"dgrad1_gen", gen)
+        try:
+            mod.zero_grad(set_to_none=True)
+            pred, hidden = mod.forward_prepared(xs, graph)
+            (R.functional.mse_loss(pred, y) + (hidden ** 2).mean()).backward()
+            got = {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}
+        finally:
+            lib.regt_set_option(b"dgrad1_gen", prev)
+        if gen in res:
+            assert all(torch.equal(got[k], res[gen][k]) for k in got)          # the generated path is bit-reproducible
+        res[gen] = got
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        if k == "tgnn._attention":
+            scale = float(res[0][k].abs().max())
+            assert float((res[0][k] - res[1][k]).abs().max()) <= 1e-5 * scale + 1e-9
+        else:
+            assert torch.equal(res[0][k], res[1][k]), k
