@@ -293,11 +293,21 @@ struct EpiDgrad1GenF {
     EpiDgrad1 e;
     int parts;              // C / 128 column tiles
     static constexpr int ROUND_ROWS = 8;
+    // sum over the 32 lanes of a half wave (the lanes that share a tile row), in a fixed order, on the VALU's DPP path -- no LDS
+    // round trips: quads, 8-lane halves, 16-lane rows, then row 0's total into row 1 (row 2's into row 3).  The total ends up in
+    // lanes 16-31 / 48-63; lane 31 / 63 stores it.
     __device__ __forceinline__ static float half_wave_sum(float s) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+#define REGT_DPP_ADD(ctrl, rmask) s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), ctrl, rmask, 0xF, true))
+        REGT_DPP_ADD(0xB1, 0xF);     // quad_perm [1, 0, 3, 2]
+        REGT_DPP_ADD(0x4E, 0xF);     // quad_perm [2, 3, 0, 1]
+        REGT_DPP_ADD(0x141, 0xF);    // row_half_mirror
+        REGT_DPP_ADD(0x140, 0xF);    // row_mirror
+        REGT_DPP_ADD(0x142, 0xA);    // row_bcast:15 into rows 1 and 3
+#undef REGT_DPP_ADD
         return s;
     }
+    static constexpr int SUM_LANE = 31;
+    static constexpr int EPI_AUX_BYTES = 192;     // two rounds of two rows in flight (this kernel runs two workgroups per CU: 256 VGPRs)
     struct Aux { float4 h, Z, R, d, t; float p; };
     __device__ __forceinline__ Aux load(long m, int c) const {
         const long node = m / e.T;
@@ -324,7 +334,7 @@ struct EpiDgrad1GenF {
 #undef F_
         // (guarded path of a partial tile: the 32 lanes of a row take this branch together -- rows are uniform per half wave)
         const float s = half_wave_sum(REGT_GEN_DOT(a));
-        if ((threadIdx.x & 31) == 0) e.rowdot[m * parts + c / GBN] = s;
+        if ((threadIdx.x & 31) == SUM_LANE) e.rowdot[m * parts + c / GBN] = s;
     }
     static constexpr int NVAR = 1;
     static constexpr bool HAS_ROWTAB = true;
@@ -379,7 +389,7 @@ struct EpiDgrad1GenF {
         buf_st4(t.dzr, t.vzr + i * t.szr, 0, REGT_V4(F_));
 #undef F_
         const float s = half_wave_sum(REGT_GEN_DOT(a));
-        if ((threadIdx.x & 31) == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), t.rd, t.vrd + i * t.srd, 0, 0);
+        if ((threadIdx.x & 31) == SUM_LANE) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s), t.rd, t.vrd + i * t.srd, 0, 0);
     }
 #undef REGT_GEN_DOT
 };

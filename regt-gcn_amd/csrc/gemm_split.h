@@ -65,6 +65,10 @@ constexpr int SP_LDS_BYTES = SplitGeom<3>::LDS_BYTES;
 // on 16 distinct 16-B bank quads; ds_write_b64 in 16 consecutive lanes = 4 rows x 4 k-quads = 32 distinct banks.
 __device__ __forceinline__ constexpr int sp_off(int r, int g) { return r * SP_ROW_B + ((g ^ ((r >> 3) & 1)) << 4); }
 
+// F::EPI_AUX_BYTES if the functor declares it, else 96 (the budget of the 168-VGPR, three-workgroup kernels)
+template <class F> constexpr auto epi_aux_budget(int) -> decltype(F::EPI_AUX_BYTES) { return F::EPI_AUX_BYTES; }
+template <class F> constexpr int epi_aux_budget(long) { return 96; }
+
 template <bool REGION, int NP = 3>
 struct SplitCore : FastCore<true, REGION> {
     using Base = FastCore<true, REGION>;
@@ -896,7 +900,8 @@ struct SplitCore : FastCore<true, REGION> {
     __device__ __forceinline__ void vec_body_halves(f32x16 (&acc)[2][2], const F& f) const {
         // (a thread owns 8 rows of each half; two rounds in flight within ~48 registers: 8, 4, 2 or 1 rows per round)
         constexpr int AB = (int)sizeof(typename F::VAux);
-        constexpr int RR = AB * 8 <= 96 ? 8 : (AB * 4 <= 96 ? 4 : (AB * 2 <= 96 ? 2 : 1)), RPH = 8 / RR, NR = 2 * RPH;
+        constexpr int BUDGET = epi_aux_budget<F>(0);      // bytes of auxiliary operands per round (functors of 2-workgroup kernels ask for more)
+        constexpr int RR = AB * 8 <= BUDGET ? 8 : (AB * 4 <= BUDGET ? 4 : (AB * 2 <= BUDGET ? 2 : 1)), RPH = 8 / RR, NR = 2 * RPH;
         const EpiGeom geo{rm.base, n0, tid >> 5, 4 * (tid & 31), 8, Base::rowtab()};
         const typename F::Tile tl = f.template vtile<V>(geo);
         const typename F::Col col = f.template vcol<V>(Base::ecol());
