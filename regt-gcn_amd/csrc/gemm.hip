@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
 
 // dgrad_candidate with its left operand generated on the way (SplitCore::run_u_gen + EpiDgrad1GenF): cell_bwd_kernel and the candidate
 // data gradient in one launch.  fp32 arithmetic; two workgroups per CU (three operand arrays in flight per A slot).
-__global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi) {
+__global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi, int rotate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -875,7 +875,10 @@ __global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, lon
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const SplitCore<false, 0>::AGen g{epi.e.ZR, epi.e.Ht, epi.e.dOH, epi.e.dhp, epi.e.C, (unsigned)epi.e.num_nodes * (unsigned)epi.e.C * 4u};
-    core.run_u_gen(acc, g);
+    // k walk of this column tile: natural order (rotate = 1, an experiment that lost: start behind the tile's own columns)
+    const int nslab = epi.e.C / GBK;
+    const int rot = rotate ? ((n0 + GBN) / GBK) % nslab : 0;
+    core.run_u_gen(acc, g, rot);
     core.for_each_vec_halves(acc, epi);
 }
 
@@ -1148,7 +1151,9 @@ int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e,
     REGT_CHECK_ARG(a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh) && a16(e.Ht) && a16(e.dhp), "dgrad1 (generated operand): 16-byte aligned arrays");
     const long tiles = (long)cdiv(M, GBM) * (N / GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-    hipLaunchKernelGGL(gemm_dgrad1_gen_kernel, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN});
+    static int rotate = -1;
+    if (rotate < 0) { const char* r = getenv("REGT_DGRAD1_ROT"); rotate = r ? atoi(r) : 0; }
+    hipLaunchKernelGGL(gemm_dgrad1_gen_kernel, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

@@ -392,49 +392,51 @@ struct SplitCore : FastCore<true, REGION> {
 #pragma unroll
         for (int j = 0; j < 2; ++j) rb[h + 2 * j] = buf_ld4(d.b, d.vb[j], d.sb + 64 * h);
     }
-    // run_u's schedule with generated A slots; ONE segment (its B = the weights, [N][K]; its A pointer is not read), K % 32 == 0
-    __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g) {
+    // run_u's schedule with generated A slots; ONE segment (its B = the weights, [N][K]; its A pointer is not read), K % 32 == 0.
+    // `rot` > 0 walks the k slabs rotated by that many slabs (experiment, REGT_DGRAD1_ROT=1: the tile's own 128 columns last, so
+    // that the epilogue's second read of Z / H~ of those columns might still hit the XCD's L2 -- measured WORSE: the two column
+    // tiles of a row tile then no longer fetch the same slab at the same time and stop sharing their A rows through L2:
+    // 10.3 instead of 7.6 GB fetched per launch, 2.73 instead of 2.65 ms; profiles/r04_gen_pmc.txt).
+    __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g, int rot) {
         static_assert(NP == 0, "generated A operand: fp32 core");
         nreg_u = 0;
         const int nslab = S.seg[0].K / GBK;
         if (nslab == 0) return;
         const bool writer = n0 == 0;
+        auto kof = [&](int i) { int q = i + rot; if (q >= nslab) q -= nslab; return q * GBK; };      // k0 of the i-th slab walked
         __syncthreads();                            // the row table (fill_rowtab) is complete
         const GenRows rows = gen_rows(g);
         GenRegs q;
         float4 rb[4];
-        SegCursor c{0, 0, 0};
-        int k_held = 0;
+        int k_held = kof(0);
         {
-            const SrdsU d = make_u(c, true);
+            const SrdsU d = make_u(SegCursor{0, 0, k_held}, true);
             const GenSrd s = gen_srd(g, true, writer);
-            gen_load_half(0, s, rows, 0, q);
-            gen_load_half(1, s, rows, 0, q);
+            gen_load_half(0, s, rows, k_held, q);
+            gen_load_half(1, s, rows, k_held, q);
             load_b_half(0, d, rb);
             load_b_half(1, d, rb);
-            gen_store_half(0, s, rows, 0, q, rb);
-            gen_store_half(1, s, rows, 0, q, rb);
+            gen_store_half(0, s, rows, k_held, q, rb);
+            gen_store_half(1, s, rows, k_held, q, rb);
         }
         {
             const bool two = nslab > 1;
-            if (two) cursor_next(c);
-            const SrdsU d = make_u(c, two);
+            k_held = kof(two ? 1 : 0);
+            const SrdsU d = make_u(SegCursor{0, 0, k_held}, two);
             const GenSrd s = gen_srd(g, two, writer);
-            gen_load_half(0, s, rows, GBK, q);
-            gen_load_half(1, s, rows, GBK, q);
+            gen_load_half(0, s, rows, k_held, q);
+            gen_load_half(1, s, rows, k_held, q);
             load_b_half(0, d, rb);
             load_b_half(1, d, rb);
-            k_held = GBK;
         }
         __syncthreads();
         compute(0, acc);
         const GenSrd sw = gen_srd(g, true, writer);      // for the stores of the held slab (always a live one)
         for (int it = 0; it + 1 < nslab; ++it) {
             const bool live = it + 2 < nslab;
-            if (live) cursor_next(c);
-            const SrdsU nx = make_u(c, live);
+            const int k_next = kof(live ? it + 2 : 0);
+            const SrdsU nx = make_u(SegCursor{0, 0, k_next}, live);
             const GenSrd sn = gen_srd(g, live, writer);
-            const int k_next = (it + 2) * GBK;
             __syncthreads();
             fused_gen(0, 1, nx, sn, sw, rows, k_held, k_next, q, rb, acc);
             __syncthreads();
