@@ -331,7 +331,7 @@ def stage_flops(stage, M, C, F):
     }.get(stage)
 
 
-def stage_bytes(stage, M, C, F, mode=0, xbf=False):
+def stage_bytes(stage, M, C, F, mode=0, xbf=False, gen=False):
     """Algorithmic HBM bytes of one launch: every activation operand read once, every result written once; weights and
     per-node vectors are negligible.  fp32 storage (4 B) except under GEMM mode 2 (bf16), where the M x C activations
     (h, [Z|R], q, H~, dh, dhp, dzp|drp) are stored as bf16 (2 B); x, A_hat x, L~ x are fp32 rows unless ``xbf`` (the bf16-row
@@ -345,7 +345,9 @@ def stage_bytes(stage, M, C, F, mode=0, xbf=False):
         "fused_forward": x * 3 * F + a * 5 * C,                     # read x, L~ x, A_hat x; write h, [Z|R], q, H~ -- nothing read back
         "fused_backward": a * 4 * C + a * 4 * C,                    # read Z, R, h, H~; write dhp, dzp, drp, ds
         "cell_bwd": a * 3 * C + a * 2 * C,                          # read Z, h, H~; write dhp, dzp
-        "dgrad_candidate": a * (C + C + 2 * C) + a * 2 * C,         # read dhp, h, Z, R; write drp, dh
+        # two launches: read dhp, h, Z, R; write drp, dh.  `gen` (fp32, round 4: cell_bwd folded in, gemm_dgrad1_gen_kernel):
+        # read Z, H~, h, R; write dhp, dzp, drp, dh -- the left operand is formed from Z, H~, dOH while it is staged
+        "dgrad_candidate": (a * 4 * C + a * 4 * C) if gen else (a * (C + C + 2 * C) + a * 2 * C),
         "dgrad_gates": a * (2 * C + C + C) + a * C,                 # read dzp|drp, dh, h; write ds
         "wgrad_Uzr": a * 3 * C, "wgrad_Uh": a * 2 * C, "wgrad_Gzr": a * 2 * C + x * F, "wgrad_Gh": a * C + x * F,
         "wgrad_A0_Ar": a * C + x * 2 * F,
@@ -362,6 +364,8 @@ def stage_kernel(stage, mode):
     epi = {"gemm_gates": "EpiGates", "dgrad_candidate": "EpiDgrad1", "dgrad_gates": "EpiDgrad2"}.get(stage)
     if epi:
         pats = [f"gemm_flat_split_kernel<regt::{epi}F, false, {np_}>"]
+        if stage == "dgrad_candidate" and mode == 0:
+            pats.insert(0, "gemm_dgrad1_gen_kernel")
         if mode == 2:
             pats.insert(0, f"gemm_flat_split8_kernel<regt::{epi}8F, false>")
         return pats
@@ -630,18 +634,19 @@ def main():
         }
         if stages:
             per = {}
+            gen = mode == 0 and "cell_bwd" not in stages      # fp32: cell_bwd folded into the candidate data gradient (round 4)
             for k, (c, ms) in stages.items():
                 e = {"launches": c, "avg_ms": ms / c}
                 if stage_flops(k, M, C, F):
                     e["tflops"] = stage_flops(k, M, C, F) / (ms / c * 1e-3) / 1e12
-                if stage_bytes(k, M, C, F, mode, rows_bf16):
-                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F, mode, rows_bf16) / (ms / c * 1e-3) / 1e9
+                if stage_bytes(k, M, C, F, mode, rows_bf16, gen):
+                    e["algorithmic_gbs"] = stage_bytes(k, M, C, F, mode, rows_bf16, gen) / (ms / c * 1e-3) / 1e9
                 per[k] = e
             mfma = [(ms, k) for k, (c, ms) in stages.items() if stage_flops(k, M, C, F)]
             tot_ms, dom = max(mfma)
             cnt = stages[dom][0]
             avg_s = tot_ms / cnt * 1e-3
-            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F, mode, rows_bf16)
+            fl, by = stage_flops(dom, M, C, F), stage_bytes(dom, M, C, F, mode, rows_bf16, gen)
             tflops, gbs = fl / avg_s / 1e12, by / avg_s / 1e9
             traffic, src = pmc_traffic(args.workload, mode, dom)
             mfma_peak = PEAK_FP32_MATRIX_TFLOPS if mode == 0 else PEAK_BF16_MATRIX_TFLOPS
