@@ -366,7 +366,49 @@ class ConvStackedTemporalGCN(nn.Module):
     def prepare_graph(self, edge_index, edge_attr, num_nodes: int) -> GcnOperator:
         return prepare_gcn_operator(edge_index, edge_attr, num_nodes)
 
+    # conv1 .. conv5 are applied WITHOUT an activation in between (models/ConvStackedTemporalGCN.py:116-120), and the aggregation
+    # (acts on the node axis) commutes with the linear maps (act on the feature axis), so the five layers collapse exactly:
+    #     h5 = (A^5 x) (W5 W4 W3 W2 W1)^T + sum_k (A^(5-k) 1) (W5 .. W_(k+1) b_k)^T,        A = A_hat
+    # -- five aggregations of the INPUT at width T*F (no sparse backward: x is data) and of the all-ones vector (once per graph),
+    # ONE (M x 512) GEMM with K = F + 8 on the rows [A^5 x | A^0 1 .. A^4 1], and a chain of 512 x 512 weight products that
+    # autograd differentiates (LinearFunction: regt_linear / regt_wgrad).  The reference-faithful layer-by-layer form -- four
+    # aggregations of the learned hidden state at width T*512 forward (A_hat) and backward (A_hat^T), 27 GB of gathered rows
+    # each at the cfg-3 shape -- stays available as ``collapse = False`` / :meth:`forward_layerwise` (and is what pins the wide
+    # aggregation kernels in tests/test_gpu_convstack.py); same parameters, same gradients up to fp32 reassociation.
+    collapse = True
+
     def forward_prepared(self, x: torch.Tensor, op: GcnOperator):
+        _need_cuda(x)
+        if not self.collapse:
+            return self.forward_layerwise(x, op)
+        n, f, t = x.shape
+        sd = dict(self.named_parameters())
+        u = ops.pack_x(x).view(n, t * f)                                        # (N, T*F)
+        for _ in range(5):
+            u = ops.spmm_csr(op.rowptr, op.col, op.val, u)                      # A^5 x: input data, no backward
+        chain = op.__dict__.get("_ones_chain")
+        if chain is None:                                                       # [A^0 1 .. A^4 1 | 0 0 0] per node, once per graph
+            cols, a = [], torch.ones(n, 4, device=x.device)
+            for _ in range(5):
+                cols.append(a[:, :1])
+                a = ops.spmm_csr(op.rowptr, op.col, op.val, a)
+            chain = torch.cat(cols + [torch.zeros(n, 3, device=x.device)], dim=1).contiguous()
+            op.__dict__["_ones_chain"] = chain
+        feat = torch.cat([u.view(n, t, f), chain[:, None, :].expand(n, t, 8)], dim=2).reshape(n * t, f + 8)
+        # P_k = W5 .. W_(k+1),  c_k = P_k b_k  (k = 5 .. 1),  W_all = P_1 W1
+        P = sd["tgnn.conv5.lin.weight"]
+        cs = [sd["tgnn.conv5.bias"].view(1, -1)]                                # c_5 = b_5
+        for k in (4, 3, 2, 1):
+            cs.append(LinearFunction.apply(sd[f"tgnn.conv{k}.bias"].view(1, -1), P, None))          # (P b_k)^T as a row
+            wk = sd[f"tgnn.conv{k}.lin.weight"]
+            P = _compose(P, wk)                                                 # P @ W_k
+        zero = torch.zeros(3, self.HIDDEN, device=x.device)
+        wcat = torch.cat([P.t()] + cs + [zero], dim=0).t().contiguous()         # (512, F + 8): [W_all | c_5 c_4 c_3 c_2 c_1 | 0 0 0]
+        h = LinearFunction.apply(feat, wcat, None)                              # (M, 512)
+        return CellFunction.apply(x, h, op, *[sd[k] for k in PARAM_NAMES_CELL])
+
+    def forward_layerwise(self, x: torch.Tensor, op: GcnOperator):
+        """The reference's evaluation order: every layer aggregates its (learned) input at width T*512."""
         _need_cuda(x)
         n, f, t = x.shape
         c = self.HIDDEN

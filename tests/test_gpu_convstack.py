@@ -30,8 +30,11 @@ def test_state_dict_layout_matches_reference(R):
     mod.load_state_dict(want, strict=True)
 
 
+# collapse = True: the five activation-free conv layers as ONE contraction on [A^5 x | A^j 1] (nn.ConvStackedTemporalGCN);
+# False: layer by layer, the learned hidden state aggregated at width T*512 (the reference's evaluation order)
+@pytest.mark.parametrize("collapse", [True, False], ids=["collapsed", "layerwise"])
 @pytest.mark.parametrize("tag", ["in6_out1", "in12_out3"])
-def test_convstack_matches_reference_goldens(R, tpims, tag):
+def test_convstack_matches_reference_goldens(R, tpims, tag, collapse):
     g = load_npz(f"golden_convstack_{tag}.npz")
     t_in, t_out, w0 = int(g["t_in"]), int(g["t_out"]), int(g["window"])
     p = M.init_params("ConvStackedTemporalGCN", 8, t_in, t_out, seed=int(g["seed"]))
@@ -40,6 +43,7 @@ def test_convstack_matches_reference_goldens(R, tpims, tag):
     mod = R.ConvStackedTemporalGCN(8, t_in, t_out)
     mod.load_state_dict(p, strict=True)
     mod = mod.cuda()
+    mod.collapse = collapse
     pred, hidden = mod(x.cuda(), tpims["edge_index"].cuda(), tpims["edge_attr"].cuda())
     loss = torch.mean((pred - y.cuda()) ** 2)
     loss.backward()
@@ -52,7 +56,8 @@ def test_convstack_matches_reference_goldens(R, tpims, tag):
         assert grads[name] is None
 
 
-def test_convstack_matches_oracle_on_directed_synthetic_graph(R):
+@pytest.mark.parametrize("collapse", [True, False], ids=["collapsed", "layerwise"])
+def test_convstack_matches_oracle_on_directed_synthetic_graph(R, collapse):
     n, e, f, t, o = 700, 5000, 8, 6, 2
     g = R.data.synthetic_regional_graph(n, e, 3, seed=21)          # directed edge list
     (x, y), = R.data.synthetic_snapshots(n, f, t, o, 1, seed=21)
@@ -65,6 +70,7 @@ def test_convstack_matches_oracle_on_directed_synthetic_graph(R):
     mod = R.ConvStackedTemporalGCN(f, t, o)
     mod.load_state_dict(p, strict=True)
     mod = mod.cuda()
+    mod.collapse = collapse
     pred, hidden = mod(x.cuda(), g.edge_index.cuda(), g.edge_attr.cuda())
     torch.mean((pred - y.cuda()) ** 2).backward()
     scale = max(1.0, float(hid_o.detach().abs().max()))

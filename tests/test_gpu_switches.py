@@ -25,7 +25,10 @@ def _ab(spec_b, mode, nodes, feat):
 
 
 @pytest.mark.parametrize("switch,mode,rel", [
-    ("REGT_GEMM_DESC=table", 0, 0.0),        # same kernels, descriptors from the LDS table: bit-identical
+    # same kernels, descriptors from the LDS table: bit-identical -- except that the generated-operand candidate data gradient
+    # (round 4) has no table form, so this switch also restores cell_bwd + dgrad_candidate: same dhp / dzp / drp / dh to the bit,
+    # the attention gradient summed in another fixed order (1e-5 of its scale)
+    ("REGT_GEMM_DESC=table", 0, 0.0),
     # bf16: also turns the fragment-order weights off, and with them the bf16 rows of x / A_hat x / L~ x and the fused kernels
     # (x is then aggregated unrounded and rounded at LDS staging instead of once while it is packed): same arithmetic, one
     # rounding point moved -- held to the bf16 bar of tests/test_gpu_bf16.py (8 u)
@@ -36,4 +39,6 @@ def test_switch_reproduces_default(switch, mode, rel):
     for name, diff, scale in _ab(switch, mode, 3000, 32):
         # (the attention gradient is a difference of nearly equal terms: 6 x the bar, as in tests/test_gpu_bf16.py)
         r = 6 * rel if (mode == 2 and name == "g:tgnn._attention") else rel
+        if mode == 0 and switch == "REGT_GEMM_DESC=table" and name == "g:tgnn._attention":
+            r = 1e-5
         assert diff <= r * scale + (0.0 if r == 0.0 else 1e-9), (switch, mode, name, diff, scale)
