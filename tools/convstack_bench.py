@@ -16,6 +16,7 @@ import regtgcn_amd as R
 from regtgcn_amd import _lib
 
 nodes, edges, F, T = (int(v) for v in sys.argv[1:5]) if len(sys.argv) >= 5 else (100_000, 1_000_000, 32, 12)
+COLLAPSE = os.environ.get("REGT_CONVSTACK_COLLAPSE", "1") != "0"      # 0: layer by layer, hidden state aggregated at width T*512
 lib = R.load_library()
 dev = torch.device("cuda")
 g = R.data.synthetic_regional_graph(nodes, edges, 8, seed=42)
@@ -24,6 +25,7 @@ model = R.ConvStackedTemporalGCN(F, T, 1).to(dev)
 with torch.no_grad():                       # five un-normalised 512-wide layers: keep activations O(1)
     for layer in range(2, 6):
         getattr(model.tgnn, f"conv{layer}").lin.weight.mul_(0.5)
+model.collapse = COLLAPSE
 op = model.prepare_graph(g.edge_index.to(dev), g.edge_attr.to(dev), nodes)
 snaps = [(x.to(dev), y.to(dev)) for x, y in R.data.synthetic_snapshots(nodes, F, T, 1, 2, seed=42)]
 opt = torch.optim.RMSprop(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -55,7 +57,7 @@ _lib.check(lib.regt_profile_collect(buf, 16384), "regt_profile_collect")
 M, C = nodes * T, 512
 nnz = int(op.col.numel())
 flops = 2.0 * M * C * F * 3 + 4 * 2.0 * M * C * C * 3 + 2.0 * M * (2 * C) * (C + F) * 3 + 2.0 * M * C * (C + F) * 3
-print(f"ConvStackedTemporalGCN  N={nodes} E={edges} F={F} T={T}: {1e3 * dt / K:.1f} ms/step  ({K / dt:.2f} snapshots/s), "
+print(f"ConvStackedTemporalGCN ({'collapsed conv stack' if COLLAPSE else 'layer by layer'})  N={nodes} E={edges} F={F} T={T}: {1e3 * dt / K:.1f} ms/step  ({K / dt:.2f} snapshots/s), "
       f"loss {float(loss):.4f}, ~{flops / 1e12:.1f} TFLOP/step dense => {flops / (dt / K) / 1e12:.0f} TFLOP/s overall; "
       f"hidden-state aggregation: 8 SpMMs of {nnz * T * C * 4 / 1e9:.1f} GB gathered each; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 for line in buf.value.decode().splitlines():
