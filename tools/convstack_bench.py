@@ -56,10 +56,11 @@ buf = (ctypes.c_char * 16384)()
 _lib.check(lib.regt_profile_collect(buf, 16384), "regt_profile_collect")
 M, C = nodes * T, 512
 nnz = int(op.col.numel())
-flops = 2.0 * M * C * F * 3 + 4 * 2.0 * M * C * C * 3 + 2.0 * M * (2 * C) * (C + F) * 3 + 2.0 * M * C * (C + F) * 3
+cell = 2.0 * M * (2 * C) * (C + F) * 3 + 2.0 * M * C * (C + F) * 3
+flops = (2.0 * M * C * (F + 8) * 2 + cell) if COLLAPSE else (2.0 * M * C * F * 3 + 4 * 2.0 * M * C * C * 3 + cell)
 print(f"ConvStackedTemporalGCN ({'collapsed conv stack' if COLLAPSE else 'layer by layer'})  N={nodes} E={edges} F={F} T={T}: {1e3 * dt / K:.1f} ms/step  ({K / dt:.2f} snapshots/s), "
       f"loss {float(loss):.4f}, ~{flops / 1e12:.1f} TFLOP/step dense => {flops / (dt / K) / 1e12:.0f} TFLOP/s overall; "
-      f"hidden-state aggregation: 8 SpMMs of {nnz * T * C * 4 / 1e9:.1f} GB gathered each; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+      f"{'aggregations: 5 of the input at width T*F' if COLLAPSE else f'hidden-state aggregation: 8 SpMMs of {nnz * T * C * 4 / 1e9:.1f} GB gathered each'}; peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 for line in buf.value.decode().splitlines():
     name, cnt, ms = line.split()
     print(f"  cell stage {name:18s} {float(ms) / K:8.3f} ms/step")
