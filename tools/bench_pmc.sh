@@ -2,11 +2,11 @@
 # rocprofv3 passes over bench.py (GPU box, repo root): kernel-trace stats + three PMC passes (counters in their own runs).
 #   tools/bench_pmc.sh <tag> [bench.py args...]      e.g.  tools/bench_pmc.sh cfg3 --workload cfg3
 # Writes gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_hbm_summary.txt, <tag>_pmc_sq_summary.txt, <tag>_bench.json;
-# copy the ones to be judged into profiles/ (bench.py reads profiles/r03_<workload>_pmc_hbm_summary.txt for `traffic`).
+# copy the ones to be judged into profiles/ (bench.py reads profiles/r04_<workload>_pmc_hbm_summary.txt for `traffic`).
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out
-common="--no-cpu-baseline --no-split-leg --no-tpims-leg"
+common="--no-cpu-baseline --no-split-leg --no-tpims-leg --no-cfg5-leg"
 python3 bench.py "$@" --steps 20 --warmup 3 $common > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { echo "plain bench failed"; tail -5 gpurun_out/${tag}_bench.err; exit 1; }
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_kt -- python3 bench.py "$@" --steps 12 --warmup 3 $common > gpurun_out/${tag}_kt.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 gpurun_out/${tag}_kt.log; exit 1; }
