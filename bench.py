@@ -248,7 +248,7 @@ def tpims_leg(dev, steps=300, warmup=30, with_cpu=True):
     ei_d, ri_d, rw_d = fx["edge_index"].to(dev), [fx[f"edge_{r}_index"].to(dev) for r in regs], [fx[f"edge_{r}_attr"].to(dev) for r in regs]
     graphs = R.train.BatchedGraphs(lambda b: model.prepare_graph(ei_d, ri_d, rw_d, copies=b))
     batched = {}
-    for B in (16, 64):
+    for B in (16, 64, 256):
         reps = (4 * B + len(xs) - 1) // len(xs)
         store = R.train.WindowStore((xs * reps)[:4 * B], (ys * reps)[:4 * B])       # 4 batches per "epoch"
         epochs = max(2, steps // (4 * B) + 1)
