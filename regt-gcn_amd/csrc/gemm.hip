@@ -2541,17 +2541,76 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 // Eight adjacent lanes share one output element: the chunk range is strided over them and combined with
 // a fixed xor-shuffle tree, so the order of the additions is fixed (deterministic) and small outputs
 // (the C x F gradients) still fill the chip.
+// 16-byte form of the main part (round 4): a lane owns FOUR consecutive output elements (one float4 per chunk: a quarter of the load
+// instructions, 512 contiguous bytes per 32-lane group and chunk), a workgroup 128.  Every element is summed over the same chunks in
+// the same order and the eight partial sums meet in the same tree as in the scalar form below: bit-identical results.  Needs
+// Nin % 4 == 0 and 16-byte aligned slab rows / output rows (wgrad_reduce_vec_ok).
+__device__ __forceinline__ bool wgrad_reduce_vec_ok(const WgradReduceArgs& a) {
+    return a.Nin % 4 == 0 && a.slab_stride % 4 == 0 && a.elem_offset % 4 == 0 && (a.slab_ld == 0 || a.slab_ld % 4 == 0) && a.ldo % 4 == 0 &&
+           a.group_stride % 4 == 0 && ((reinterpret_cast<unsigned long long>(a.slab) | reinterpret_cast<unsigned long long>(a.out)) & 15) == 0;
+}
+__device__ __forceinline__ void wgrad_reduce_main_v4(const WgradReduceArgs& a, long block, long nblocks, float4 (*part)[33]) {
+    const long per = (long)a.Nout * a.Nin;
+    const long total = per * a.ngroups;
+    const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
+    for (long base = block * 128; base < total; base += nblocks * 128) {
+        const long idx = base + 4 * el;
+        const bool valid = idx < total;                 // total % 4 == 0: a float4 never straddles the end (or a row: Nin % 4 == 0)
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int g = 0;
+        long e = 0;
+        if (valid) {
+            g = (int)(idx / per);
+            e = idx - (long)g * per;
+            const long se = a.slab_ld ? (e / a.Nin) * a.slab_ld + e % a.Nin : e;
+            const float* p = a.slab + a.elem_offset + se;
+            int c = sub;
+#define REGT_ADD4(v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            if (!a.chunk_group) {
+                for (; c + 24 < a.nchunks; c += 32) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(p + (long)c * a.slab_stride);
+                    const float4 v1 = *reinterpret_cast<const float4*>(p + (long)(c + 8) * a.slab_stride);
+                    const float4 v2 = *reinterpret_cast<const float4*>(p + (long)(c + 16) * a.slab_stride);
+                    const float4 v3 = *reinterpret_cast<const float4*>(p + (long)(c + 24) * a.slab_stride);
+                    REGT_ADD4(v0) REGT_ADD4(v1) REGT_ADD4(v2) REGT_ADD4(v3)
+                }
+            }
+            for (; c < a.nchunks; c += 8)
+                if (!a.chunk_group || a.chunk_group[c] == g + a.group_base) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (long)c * a.slab_stride);
+                    REGT_ADD4(v)
+                }
+#undef REGT_ADD4
+        }
+        part[sub][el] = s;
+        __syncthreads();
+        if (valid && sub == 0) {
+#define REGT_TREE(k) (((part[0][el].k + part[1][el].k) + (part[2][el].k + part[3][el].k)) + ((part[4][el].k + part[5][el].k) + (part[6][el].k + part[7][el].k)))
+            s = make_float4(REGT_TREE(x), REGT_TREE(y), REGT_TREE(z), REGT_TREE(w));
+#undef REGT_TREE
+            const int i = (int)(e / a.Nin), j = (int)(e % a.Nin);
+            float4* o = reinterpret_cast<float4*>(a.out + (long)g * a.group_stride + (long)i * a.ldo + j);
+            if (a.accumulate) { const float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+            *o = s;
+        }
+        __syncthreads();
+    }
+}
 __device__ __forceinline__ void wgrad_reduce_body(const WgradReduceArgs& a, long block, long nblocks) {
     // A workgroup owns 32 consecutive output elements; its eight 32-lane groups each sum every eighth chunk of them (a wave
     // reads two chunks x 128 contiguous bytes per step -- with the eight partial sums of an element in ADJACENT lanes a wave
     // touched eight chunks x 32 bytes), and the eight partial sums meet in LDS in the association of the former xor-shuffle
     // tree: ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  Results are bit-identical to the shuffle version.
-    __shared__ float part[8][33];
+    __shared__ float4 part4[8][33];
+    float (*part)[33] = reinterpret_cast<float (*)[33]>(&part4[0][0]);
     const long per = (long)a.Nout * a.Nin;
     const long total = per * a.ngroups;
     const long ncs = a.colsum_out ? a.ncolsum : 0;
     const int sub = threadIdx.x >> 5, el = threadIdx.x & 31;
-    for (long base = block * 32; base < total + ncs; base += nblocks * 32) {
+    const bool vec = wgrad_reduce_vec_ok(a);            // (uniform: kernel arguments only)
+    if (vec) wgrad_reduce_main_v4(a, block, nblocks, part4);
+    // scalar form: everything when the block is not vectorisable, else only the column sums behind the main part
+    for (long base = (vec ? total : 0) + block * 32; base < total + ncs; base += nblocks * 32) {
         const long idx = base + el;
         const bool valid = idx < total + ncs;
         float s = 0.f;
