@@ -189,7 +189,19 @@ struct CallScope {
 };
 // workspace formats remembered between forward and backward (note_q_format): bit 0 = bf16 intermediates, bit 1 = bf16 rows of
 // x / A_hat x / L~ x, bit 2 = the packed input was the CALLER's bf16 buffer (else the rounded copy lives in the workspace)
-enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4 };
+enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4, FMT_TCOLLAPSE = 8 };
+// TemporalGCN / A3T-GCN (regional = 0): the hidden input h = x W0^T + (L~ x) W1^T + b has NO activation (models/TemporalGCN.py:88 --
+// RegT-GCN applies leaky_relu, RegionalTemporalGCN.py:143), so wherever the gates use h LINEARLY it folds into the input:
+//     h [Uz2; Ur2]^T = x ([Uz2; Ur2] W0)^T + (L~ x) ([Uz2; Ur2] W1)^T + ([Uz2; Ur2] b)^T
+// -- the gate GEMM runs at K = 3 F instead of C + F, and in the backward pass the K = 2 C data gradient of the gates (ds, which only
+// ever fed weight gradients of that linear map) and the (2C x C) weight gradient dzr^T h become (2C x F) contractions on x and L~ x
+// plus tiny compositions.  h itself is still formed: the reset gate multiplies it (q = h * R) and the blend reads it.
+// REGT_TGCN_COLLAPSE=0 / regt_set_option("tgcn_collapse", 0): the uncollapsed form (A/B, tests).
+int g_opt_tcollapse = -1;
+bool tcollapse_wanted() {
+    if (g_opt_tcollapse < 0) { const char* e = getenv("REGT_TGCN_COLLAPSE"); g_opt_tcollapse = e ? atoi(e) : 1; }
+    return g_opt_tcollapse != 0;
+}
 inline const float* byte_off(const float* p, long bytes) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + bytes); }
 
 // bf16 mode with bf16-stored activations: the GEMM weights get per-step bf16 copies in MFMA fragment order (SEG_B_FRAG: every
@@ -241,6 +253,8 @@ struct Layout {
     // saved by forward
     float *Xp, *AX, *LX, *h, *ZR, *q, *Ht, *y1, *probs;
     float *A0, *Aall, *bprime, *Gzr, *Gh, *czr, *ch;
+    float *P0zr, *P1zr, *czr2;    // FMT_TCOLLAPSE: [Uz2; Ur2] W0, [Uz2; Ur2] W1 (2C x F each), czr + [Uz2; Ur2] b (2C)
+    float *dP01;                  // ... and the gradient of [P0 | P1] (2C x 2F)
     float *S;    // (C, C): sum of the region blocks of tgnn.linear.weight (forward, reused by backward)
     float *G0;   // (C, C): the part of d tgnn.linear.weight every region block shares (backward)
     // backward temporaries
@@ -281,6 +295,10 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.Gh = take(C * F);
     L.czr = take(2 * C);
     L.ch = take(C);
+    L.P0zr = take(2 * C * F);
+    L.P1zr = take(2 * C * F);
+    L.czr2 = take(2 * C);
+    L.dP01 = take(2 * C * 2 * F);
     L.UT = take(3 * C * C);
     // bf16 copies of the GEMM weights in MFMA fragment order (REGT_GEMM_MODE=bf16, weights_frag()): Uz, Ur, Uh, UT x 3 (C x C
     // each), Gzr (2C x F), Gh (C x F), A0 (C x F), A_r (R x (C x F)); rows padded to 128 -- sized in floats
@@ -313,7 +331,8 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
     long slab = (long)L.nchunks * (C * C + C) + (long)L.nchunks * (2 * C * C + 2 * C)
               + (long)L.nchunks_s * (C * F) + (long)L.nchunks_s * (2 * C * F) + (long)L.nchunks_s * (C * F + C)
-              + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64;
+              + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64
+              + (long)L.nchunks_s * (2 * C * 2 * F + 2 * C) + 64;        // FMT_TCOLLAPSE: dzr^T [x | L~ x] (one or two launches)
     const long ar_uniform = (long)L.nchunks_s * C * F, ar_tab = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
     slab += ar_tab > ar_uniform ? ar_tab : ar_uniform;
     slab += (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * (C * F + C);     // fused dA0 | dA_r slabs over the region chunk table
@@ -378,7 +397,7 @@ void region_range(const regt_dims& d, const regt_graph& g, int* lo, int* hi) {
     if (g.region_hi > g.region_lo && g.region_lo >= 0 && g.region_hi <= d.R) { *lo = g.region_lo; *hi = g.region_hi; }
 }
 
-int compose_forward(const regt_dims& d, const regt_graph& g, const regt_params& p, const Layout& L, hipStream_t st) {
+int compose_forward(const regt_dims& d, const regt_graph& g, const regt_params& p, const Layout& L, hipStream_t st, bool tcol = false) {
     const int C = d.C, F = d.F, R = d.R;
     const long RC = (long)R * C;
     SgBatch b{};
@@ -398,6 +417,16 @@ int compose_forward(const regt_dims& d, const regt_graph& g, const regt_params& 
         // G_k = U_k[:, :C] V_k ;  c_k = U_k[:, :C] beta_k + u_k
         add_task(b, G, F, 1, 0, C, F, 1, nullptr, 0, {term(p.gate_w[k], 2L * C, 1, 0, p.conv_lin_w[k], F, 1, 0, C)});
         add_task(b, c, 1, 0, 0, C, 1, 1, p.gate_b[k], 1, {term(p.gate_w[k], 2L * C, 1, 0, p.conv_bias[k], 1, 0, 0, C)});
+    }
+    if (tcol) {
+        for (int k = 0; k < 2; ++k) {
+            const float* U2 = p.gate_w[k] + C;          // (C x C), row stride 2C: the H half of linear_z / linear_r
+            // P0_k = U_k2 W0 ; P1_k = U_k2 W1 ; c'_k = u_k + U_k1 beta_k + U_k2 b
+            add_task(b, L.P0zr + (long)k * C * F, F, 1, 0, C, F, 1, nullptr, 0, {term(U2, 2L * C, 1, 0, p.cheb_w0, F, 1, 0, C)});
+            add_task(b, L.P1zr + (long)k * C * F, F, 1, 0, C, F, 1, nullptr, 0, {term(U2, 2L * C, 1, 0, p.cheb_w1, F, 1, 0, C)});
+            add_task(b, L.czr2 + (long)k * C, 1, 0, 0, C, 1, 1, p.gate_b[k], 1,
+                     {term(p.gate_w[k], 2L * C, 1, 0, p.conv_bias[k], 1, 0, 0, C), term(U2, 2L * C, 1, 0, p.cheb_bias, 1, 0, 0, C)});
+        }
     }
     return launch_small_gemm_multi(b, st);
 }
@@ -445,7 +474,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         hipStream_t sc = side_fork(st);
         PROF("compose_fwd", sc);
         TRY(launch_softmax_small(p.attention, L.probs, T, sc));
-        TRY(compose_forward(d, g, p, L, sc));
+        TRY(compose_forward(d, g, p, L, sc, (fmt & FMT_TCOLLAPSE) != 0));
     }
     if (fmt & FMT_XBF) {
         // bf16 rows of x, A_hat x, L~ x + the fused cell kernel (fused.hip)
@@ -552,12 +581,17 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         if (wfr) {
             S.seg[0] = make_seg(H, C, wb.U[0], wb.U[1], C, C, C, true, SEG_A_BF16 | SEG_B_FRAG);
             S.seg[1] = make_seg(L.AX, F, wb.Gzr, nullptr, F, INT_MAX, F, true, SEG_B_FRAG);
+        } else if (fmt & FMT_TCOLLAPSE) {      // K = 3 F: the linear hidden input folded into x and L~ x
+            S.nseg = 3;
+            S.seg[0] = make_seg(Xp, F, L.P0zr, nullptr, F, INT_MAX, F, true);
+            S.seg[1] = make_seg(L.LX, F, L.P1zr, nullptr, F, INT_MAX, F, true);
+            S.seg[2] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         } else {
             S.seg[0] = make_seg(H, C, p.gate_w[0] + C, p.gate_w[1] + C, 2L * C, C, C, true, abf ? SEG_A_BF16 : 0);
             S.seg[1] = make_seg(L.AX, F, L.Gzr, nullptr, F, INT_MAX, F, true);
         }
         S.row_div = T;
-        EpiGates e{L.ZR, H, L.q, L.czr, C};
+        EpiGates e{L.ZR, H, L.q, (fmt & FMT_TCOLLAPSE) ? L.czr2 : L.czr, C};
         e.q_bf16 = qbf; e.h_bf16 = abf; e.zr_bf16 = abf;
         PROF("gemm_gates", st);
         TRY(launch_gemm_gates(S, M, 2 * C, e, st));
@@ -773,6 +807,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     const int N = d.N, T = d.T, F = d.F, C = d.C, R = d.R;
     const long M = (long)N * T;
     const int qbf = fmt & FMT_QBF, xbf = (fmt & FMT_XBF) ? 1 : 0;     // xbf: x, A_hat x, L~ x hold bf16 rows (the forward's format)
+    const bool tcol = (fmt & FMT_TCOLLAPSE) != 0 && !h_ext;            // TemporalGCN: the gates' linear use of h folded into x, L~ x
     const float* Xp = (xp_ext && (!xbf || (fmt & FMT_XCALLER))) ? xp_ext : L.Xp;
     const float* H = h_ext ? h_ext : L.h;
     float* DH = dh_ext ? dh_ext : L.dh;
@@ -861,7 +896,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(launch_gemm_dgrad1(S, M, C, e, st));
     }
     }
-    {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)
+    if (!tcol) {   // ds = (dh + dzp Uz2 + drp Ur2) * act'(h)      (FMT_TCOLLAPSE: never formed -- dh alone feeds dW0 / dW1 / db below)
         GemmSegs S{};
         S.nseg = 2;
         if (wfr) {      // (drp first: the accumulation order of the fused kernel, which multiplies drp while dzp is still on its way)
@@ -891,7 +926,27 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
     TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
     TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
-    {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
+    if (tcol) {
+        // [dP0 | dP1] = dzr^T [x | L~ x]  (2C x 2F), column sums -> [dcz; dcr]: what is left of dzr^T h (the composition backward
+        // below turns it into dUz2 / dUr2 / dW0 / dW1 / db).  One launch with a two-part right-hand side when F is a multiple of
+        // the 32-column tile, else one launch per part.
+        const bool two = F % 32 == 0;
+        for (int part = 0; part < (two ? 1 : 2); ++part) {
+            WgradArgs a{L.dzr, 2L * C, 2 * C, part ? L.LX : Xp, F, two ? 2 * F : F, 0, M, L.kchunk_s, nullptr, L.nchunks_s, nullptr, part == 0 ? 1 : 0};
+            if (two) { a.Q2 = L.LX; a.ldq2 = F; a.nin_split = F; }
+            TRY(rq.take((long)L.nchunks_s * wgrad_slab_stride(a), &a.slab));
+            {
+                PROF("wgrad_P01", st);
+                TRY(launch_wgrad(a, st));
+            }
+            WgradReduceArgs r{};
+            r.slab = a.slab; r.nchunks = L.nchunks_s; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+            r.Nout = 2 * C; r.Nin = two ? 2 * F : F; r.ngroups = 1;
+            r.out = L.dP01 + (two ? 0 : part * F); r.ldo = 2L * F;
+            r.colsum_out = part == 0 ? L.dczr : nullptr; r.colsum_offset = (long)2 * C * (two ? 2 * F : F); r.ncolsum = 2 * C;
+            TRY(rq.push(r));
+        }
+    } else {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
         WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
         a.p_bf16 = ibf; a.q_bf16 = abf;
         TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
@@ -992,6 +1047,25 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         SgBatch b{};
         for (int k = 0; k < 3; ++k)      // du_k = dc_k
             add_task(b, gr.gate_b[k], 1, 0, 0, C, 1, 1, k < 2 ? L.dczr + (long)k * C : L.dch, 1, {});
+        if (tcol) {
+            // back through P0_k = U_k2 W0, P1_k = U_k2 W1, c'_k = c_k + U_k2 b  (k = z, r):
+            //   dU_k2 = dP0_k W0^T + dP1_k W1^T + dc_k b^T ;  dW0 += sum_k U_k2^T dP0_k ;  dW1 += sum_k U_k2^T dP1_k ;  db += sum_k U_k2^T dc_k
+            // (dW0 / dW1 / db already hold the direct path dh^T x / dh^T L~ x / colsum dh from the slab reduction above: added in place;
+            // the last three stated transposed -- output "rows" f, "columns" c -- so that lanes walk the contiguous index of U_k2)
+            const float* dP0[2] = {L.dP01, L.dP01 + (long)C * 2 * F};
+            const float* dP1[2] = {L.dP01 + F, L.dP01 + (long)C * 2 * F + F};
+            const float* dc[2] = {L.dczr, L.dczr + C};
+            for (int k = 0; k < 2; ++k)
+                add_task(b, gr.gate_w[k] + C, 2L * C, 1, 0, C, C, 1, nullptr, 0,
+                         {term(dP0[k], 2L * F, 1, 0, p.cheb_w0, 1, F, 0, F), term(dP1[k], 2L * F, 1, 0, p.cheb_w1, 1, F, 0, F),
+                          term(dc[k], 1, 0, 0, p.cheb_bias, 0, 1, 0, 1)});
+            add_task(b, gr.cheb_w0, 1, F, 0, F, C, 1, gr.cheb_w0, 1,
+                     {term(dP0[0], 1, 2L * F, 0, p.gate_w[0] + C, 2L * C, 1, 0, C), term(dP0[1], 1, 2L * F, 0, p.gate_w[1] + C, 2L * C, 1, 0, C)}, F);
+            add_task(b, gr.cheb_w1, 1, F, 0, F, C, 1, gr.cheb_w1, 1,
+                     {term(dP1[0], 1, 2L * F, 0, p.gate_w[0] + C, 2L * C, 1, 0, C), term(dP1[1], 1, 2L * F, 0, p.gate_w[1] + C, 2L * C, 1, 0, C)}, F);
+            add_task(b, gr.cheb_bias, 1, 0, 0, C, 1, 1, gr.cheb_bias, 1,
+                     {term(p.gate_w[0] + C, 1, 2L * C, 0, dc[0], 1, 0, 0, C), term(p.gate_w[1] + C, 1, 2L * C, 0, dc[1], 1, 0, 0, C)});
+        }
         if (d.regional) {
             const long RC = (long)R * C;
             int lo, hi;
@@ -1046,6 +1120,7 @@ int32_t regt_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);
+    if (!strcmp(name, "tgcn_collapse")) { const int prev = tcollapse_wanted() ? 1 : 0; g_opt_tcollapse = value ? 1 : 0; return prev; }
     set_error("regt_set_option: unknown option '%s'", name);
     return -1;
 }
@@ -1155,6 +1230,7 @@ static int32_t forward_common(const regt_dims* dims, const regt_graph* graph, co
     hipStream_t hs = (hipStream_t)st;
     int fmt = bf16_intermediates(*dims) ? FMT_QBF : 0;
     if (fmt && xbf_ok(*dims, *graph, false, xp_ext ? x_rows : dims->N, xp_ext && !xp_is_bf16)) fmt |= FMT_XBF | (xp_is_bf16 ? FMT_XCALLER : 0);
+    if (!dims->regional && !graph->overlap && !(fmt & FMT_QBF) && tcollapse_wanted()) fmt |= FMT_TCOLLAPSE;
     REGT_CHECK_ARG(!xp_is_bf16 || (fmt & FMT_XBF), "regt_forward_packed_bf16: bf16 input rows need REGT_GEMM_MODE=bf16 and a shape the fused "
                    "forward covers (C = 256, F = 64, node-disjoint regions, merged operator)");
     note_q_format(ws, fmt);

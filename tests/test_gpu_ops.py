@@ -275,3 +275,40 @@ def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, 
             assert float((res[0][k] - res[1][k]).abs().max()) <= 1e-5 * scale + 1e-9
         else:
             assert torch.equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("n,e,f,t,o", [(3000, 24000, 32, 12, 1), (1409, 9000, 8, 6, 2), (104, 400, 8, 12, 1)])
+def test_temporal_gcn_collapsed_gates_equal_the_uncollapsed_form(n, e, f, t, o):
+    """TemporalGCN's hidden input has no activation (models/TemporalGCN.py:88), so the gates' use of it folds into x and L~ x
+    (api.hip: FMT_TCOLLAPSE -- gate GEMM at K = 3F, no K = 2C data gradient, no (2C x C) weight gradient in the backward pass).
+    Same function, reassociated: outputs within 2e-6, every gradient within 2e-5 of its scale of the uncollapsed form
+    (regt_set_option("tgcn_collapse", 0)); F = 32 (two-part right-hand side), F = 8 (one launch per part), a TPIMS-sized graph."""
+    import regtgcn_amd as R
+    from oracle import model as M
+    from test_gpu_model import _synthetic
+    lib = R.load_library()
+    ei, ri, rw, x = _synthetic(n, e, 2, f, t, seed=n)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(1)).cuda()
+    p = M.init_params("TemporalGCN", f, t, o, seed=3)
+    mod = R.TemporalGCN(node_features=f, periods=t, output_dim=o)
+    mod.load_state_dict(p, strict=True)
+    mod = mod.cuda()
+    w = torch.rand(ei.shape[1], generator=torch.Generator().manual_seed(2)) * 100 + 1
+    graph = mod.prepare_graph(ei.cuda(), w.cuda(), n)
+    xs = x.cuda()
+    res = {}
+    for col in (1, 0):
+        prev = lib.regt_set_option(b"tgcn_collapse", col)
+        try:
+            mod.zero_grad(set_to_none=True)
+            pred, hidden = mod.forward_prepared(xs, graph)
+            (R.functional.mse_loss(pred, y) + (hidden ** 2).mean()).backward()
+            res[col] = (pred.detach().clone(), hidden.detach().clone(), {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None})
+        finally:
+            lib.regt_set_option(b"tgcn_collapse", prev)
+    assert float((res[1][0] - res[0][0]).abs().max()) < 2e-6 * max(1.0, float(res[0][0].abs().max()))
+    assert float((res[1][1] - res[0][1]).abs().max()) < 2e-6 * max(1.0, float(res[0][1].abs().max()))
+    assert set(res[1][2]) == set(res[0][2])
+    for k, g0 in res[0][2].items():
+        scale = max(float(g0.abs().max()), 1e-12)
+        assert float((res[1][2][k] - g0).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((res[1][2][k] - g0).abs().max()), scale)

@@ -8,7 +8,9 @@ import regtgcn_amd as R
 
 nodes, edges, F, T = 100_000, 1_000_000, 32, 12
 dev = torch.device("cuda")
-R.load_library()
+lib = R.load_library()
+if os.environ.get("REGT_TGCN_COLLAPSE") == "0":
+    print("uncollapsed gates (REGT_TGCN_COLLAPSE=0)")
 g = R.data.synthetic_regional_graph(nodes, edges, 8, seed=42)
 torch.manual_seed(42)
 model = R.TemporalGCN(F, T, 1).to(dev)
