@@ -318,7 +318,8 @@ int32_t regt_set_gemm_mode(int32_t mode);
  * arithmetic as one kernel.  "spmm_rows" (default 0 -- opt-in, measured slower): the row-block aggregation kernel (CSR entries of a
  * workgroup's rows held in LDS) instead of the column-panel kernels.  "dgrad1_gen" (default 1): fp32 arithmetic, the candidate data gradient
  * forms its left operand dhp from Z, H~, dOH while staging it and its epilogue writes dzp and the attention dots (no separate
- * cell-backward pass); 0 = the two launches.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
+ * cell-backward pass); 0 = the two launches.  "tgcn_collapse" (default 1): regional = 0 (TemporalGCN), fp32 / bf16x3: the gates' linear use of
+ * the activation-free hidden input folded into x and L~ x (gate GEMM at K = 3F, no K = 2C gate data gradient); 0 = uncollapsed.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
 int32_t regt_set_option(const char* name, int32_t value);
 
 /* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row
