@@ -207,10 +207,11 @@ class _FusedModel(nn.Module):
     # "fp32", "bf16x3" (exact split) or "bf16" (reduced precision, BASELINE configs[4]).  Per call, no process state: two models
     # of one process may differ.
     arithmetic = None
+    call_flags = 0        # regt_dims.flags of this model's calls: _lib.DIMS_NO_BF16_ROWS | DIMS_NO_FUSED_BWD | DIMS_NO_SIDE_STREAM (A/B switches)
 
     def _run(self, x: torch.Tensor, graph: PreparedGraph, packed: bool = False):
-        arith = _lib.arith_code(self.arithmetic)
-        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, (packed, arith, 0) if arith else packed,
+        arith, flags = _lib.arith_code(self.arithmetic), int(self.call_flags)
+        return RegTGCNFunction.apply(x, graph, self.regional, LEAKY_SLOPE, (packed, arith, flags) if (arith or flags) else packed,
                                      *self._params_in_order())
 
     def forward_packed(self, x_packed_ext: torch.Tensor, graph: PreparedGraph):

@@ -754,3 +754,37 @@ def test_snapshot_batch_equals_per_snapshot_accumulation(R, tpims, model_name):
     b_ = R.evaluate.predict_metrics_batched(mod, store, graphs, 4)
     np.testing.assert_allclose(b_, a, rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(R.train.evaluate_batched(mod, store, graphs, 4), R.train.evaluate(mod, xs, ys, graphs.get(1)), rtol=2e-5)
+
+
+def test_call_flags_are_per_call_switches():
+    """regt_dims.flags (ABI v6): REGT_DIMS_NO_SIDE_STREAM keeps every kernel of a call on the launch stream -- identical results; under
+    the bf16 arithmetic REGT_DIMS_NO_BF16_ROWS / _NO_FUSED_BWD select what regt_set_option("xbf" / "fused_bwd", 0) selects process-wide:
+    bit-identical to that path, and (the fused kernels reproduce the three-launch arithmetic) to the default one except for the
+    attention gradient's summation order."""
+    import regtgcn_amd as R
+    from regtgcn_amd import _lib
+    lib = R.load_library()
+    n, e, regions, f, t, o = 3000, 24000, 8, 64, 12, 1
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=4)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(3)).cuda()
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=5)
+
+    def run(arith, flags, option=None):
+        m = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        m.load_state_dict(p, strict=True)
+        m.arithmetic, m.call_flags = arith, flags
+        m = m.cuda()
+        graph = m.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        prev = lib.regt_set_option(option[0], option[1]) if option else None
+        try:
+            return _one_step(R, m, graph, x.cuda(), y)
+        finally:
+            if option:
+                lib.regt_set_option(option[0], prev)
+
+    base = run("fp32", 0)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(run("fp32", _lib.DIMS_NO_SIDE_STREAM), base))
+    for flag, opt in ((_lib.DIMS_NO_FUSED_BWD, b"fused_bwd"), (_lib.DIMS_NO_BF16_ROWS, b"xbf")):
+        per_call, process_wide = run("bf16", flag), run("bf16", 0, (opt, 0))
+        assert len(per_call) == len(process_wide) and all(torch.equal(a_, b_) for a_, b_ in zip(per_call, process_wide)), opt
+    assert lib.regt_set_option(b"xbf", 1) == 1 and lib.regt_set_option(b"fused_bwd", 1) == 1      # process defaults untouched
