@@ -40,6 +40,44 @@ __device__ __forceinline__ float4 f_widen4(unsigned lo, unsigned hi) {
     return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u));
 }
 struct V8 { float v[8]; };
+// Packed (two-lane) fp32 arithmetic for the epilogues: a VALU instruction of this kernel costs matrix-pipe time of its SIMD partner
+// (DESIGN 5c.1), and v_pk_add / v_pk_mul / v_pk_fma do two elements per instruction with the same IEEE results as the scalar forms.
+// The operation SEQUENCES are those of fast_sigmoid / fast_tanh (gemm.hip): mul by -log2(e), exp2, add 1, rcp -- bit for bit.
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ V8 f_sigmoid8(const V8& v, const V8& b) {
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f2_t s = {v.v[2 * i], v.v[2 * i + 1]};
+        const f2_t bb = {b.v[2 * i], b.v[2 * i + 1]};
+        s = s + bb;
+        const f2_t t = s * -1.44269502162933349609375f;            // (0xbfb8aa3b: the constant __expf(-x) multiplies by)
+        f2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        e = e + 1.0f;
+        o.v[2 * i] = __builtin_amdgcn_rcpf(e.x);
+        o.v[2 * i + 1] = __builtin_amdgcn_rcpf(e.y);
+    }
+    return o;
+}
+__device__ __forceinline__ V8 f_tanh8(const V8& v, const V8& b) {
+    V8 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f2_t s = {v.v[2 * i], v.v[2 * i + 1]};
+        const f2_t bb = {b.v[2 * i], b.v[2 * i + 1]};
+        s = s + bb;
+        s = s + s;                                                  // 2 x (exact), as fast_tanh's __expf(2.0f * x)
+        const f2_t t = s * 1.44269502162933349609375f;
+        f2_t e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        e = e + 1.0f;
+        const f2_t r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+        const f2_t one = {1.0f, 1.0f}, m2 = {-2.0f, -2.0f};
+        const f2_t h = __builtin_elementwise_fma(r, m2, one);       // 1 - 2 r as ONE fma (what hipcc contracts fast_tanh's last step into)
+        o.v[2 * i] = h.x;
+        o.v[2 * i + 1] = h.y;
+    }
+    return o;
+}
 __device__ __forceinline__ V8 f_widen8(u32x4_t r) {
     V8 o;
     o.v[0] = __uint_as_float(r.x << 16); o.v[1] = __uint_as_float(r.x & 0xffff0000u);
@@ -297,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         }
         const V8 b = bias8(a.bprime + 128 * j + ec);
         const float ns = a.act_lrelu ? a.slope : 1.0f;
+        // (tried in round 4 and measured no faster: staging and reading back round rnd + 1 before round rnd is consumed -- the LDS
+        // round trip under the arithmetic of the previous round -- 1.75 vs 1.70-1.72 ms; packed two-lane arithmetic in the gate
+        // epilogues, f_sigmoid8 / f_tanh8: 9 % fewer vector instructions, same time.  The tile's 71 k cycles are dependency
+        // latency at two waves per SIMD, not instruction count: tools/fused_trace.py)
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
@@ -327,9 +369,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             const V8 v = img8();
             const int row = 16 * rnd + er, c = 128 * j + ec;
             const V8 hv = f_widen8(*reinterpret_cast<const u32x4_t*>(Hp + plane_off(row, c)));
-            V8 g, qv;
+            const V8 g = f_sigmoid8(v, b);
+            V8 qv;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { g.v[i] = f_sigmoid(v.v[i] + b.v[i]); qv.v[i] = hv.v[i] * g.v[i]; }
+            for (int i = 0; i < 8; ++i) qv.v[i] = hv.v[i] * g.v[i];
             __builtin_amdgcn_raw_buffer_store_b128(f_pack8(g), sZR, (row * 2 * C + C + c) * 2, 0, 0);
             const u32x4_t pq = f_pack8(qv);
             __builtin_amdgcn_raw_buffer_store_b128(pq, sq, (row * C + c) * 2, 0, 0);
@@ -352,9 +395,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             for (int rnd = 0; rnd < 4; ++rnd) {
                 stage(acc, rnd);
                 const V8 v = img8();
-                V8 g;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) g.v[i] = f_sigmoid(v.v[i] + b.v[i]);
+                const V8 g = f_sigmoid8(v, b);
                 zk[rnd] = f_pack8(g);
                 __builtin_amdgcn_raw_buffer_store_b128(zk[rnd], sZR, ((16 * rnd + er) * 2 * C + 128 * j + ec) * 2, 0, 0);
             }
@@ -375,12 +416,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             const V8 hv = f_widen8(*reinterpret_cast<const u32x4_t*>(Hp + plane_off(row, c)));
             const V8 Zv = f_widen8(zk[rnd]);
             const float pt = ptr_[rnd];
-            V8 ht, bl;
+            const V8 ht = f_tanh8(v, b);
+            V8 bl;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                ht.v[i] = f_tanh(v.v[i] + b.v[i]);
-                bl.v[i] = __fmul_rn(pt, gru_blend(Zv.v[i], hv.v[i], ht.v[i]));
-            }
+            for (int i = 0; i < 8; ++i) bl.v[i] = __fmul_rn(pt, gru_blend(Zv.v[i], hv.v[i], ht.v[i]));
             __builtin_amdgcn_raw_buffer_store_b128(f_pack8(ht), sHt, (row * C + c) * 2, 0, 0);
             float4* p = reinterpret_cast<float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
             p[0] = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
