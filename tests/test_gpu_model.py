@@ -788,3 +788,41 @@ def test_call_flags_are_per_call_switches():
         per_call, process_wide = run("bf16", flag), run("bf16", 0, (opt, 0))
         assert len(per_call) == len(process_wide) and all(torch.equal(a_, b_) for a_, b_ in zip(per_call, process_wide)), opt
     assert lib.regt_set_option(b"xbf", 1) == 1 and lib.regt_set_option(b"fused_bwd", 1) == 1      # process defaults untouched
+
+
+def test_big_tile_shapes_take_the_round4_kernels():
+    """Guard against a silent fallback: at a shape with >= 128 GEMM tiles the fp32 backward runs the generated-operand candidate data
+    gradient (no cell_bwd stage), TemporalGCN runs the collapsed gates (a wgrad_P01 stage, no dgrad_gates / wgrad_Uzr), and the
+    small TPIMS shape keeps the small-tile kernels with cell_bwd (library per-stage profile, regt_profile_*)."""
+    import ctypes
+    import regtgcn_amd as R
+    from regtgcn_amd import _lib
+    lib = R.load_library()
+
+    def stages(mod, graph, x, y):
+        _one_step(R, mod, graph, x, y)                       # warm-up
+        lib.regt_profile_enable(1)
+        _one_step(R, mod, graph, x, y)
+        torch.cuda.synchronize()
+        lib.regt_profile_enable(0)
+        buf = (ctypes.c_char * 16384)()
+        _lib.check(lib.regt_profile_collect(buf, 16384), "regt_profile_collect")
+        return {ln.split()[0] for ln in buf.value.decode().splitlines()}
+
+    n, e, regions, f, t, o = 3000, 24000, 8, 32, 12, 1
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=4)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(3)).cuda()
+    m = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions).cuda()
+    g = m.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    s = stages(m, g, x.cuda(), y)
+    assert "dgrad_candidate" in s and "cell_bwd" not in s and "dgrad_gates" in s and "wgrad_Uzr" in s, s
+    tg = R.TemporalGCN(node_features=f, periods=t, output_dim=o).cuda()
+    gt = tg.prepare_graph(ei.cuda(), torch.rand(ei.shape[1]).cuda() + 1.0, n)
+    s = stages(tg, gt, x.cuda(), y)
+    assert "wgrad_P01" in s and "dgrad_gates" not in s and "wgrad_Uzr" not in s and "cell_bwd" not in s, s
+    ns = 104                                                 # TPIMS size: 10 row tiles -> small-tile kernels, two-launch cell backward
+    eis, ris, rws, xs = _synthetic(ns, 400, 5, 8, 12, seed=5)
+    ys = torch.rand(ns, 1, generator=torch.Generator().manual_seed(3)).cuda()
+    ms = R.RegionalTemporalGCN(node_features=8, num_nodes=ns, periods=12, output_dim=1, num_regions=5).cuda()
+    gs = ms.prepare_graph(eis.cuda(), [i.cuda() for i in ris], [a.cuda() for a in rws])
+    assert "cell_bwd" in stages(ms, gs, xs.cuda(), ys)
