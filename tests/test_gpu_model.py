@@ -478,8 +478,9 @@ print("OK", list(st))
 
 
 @pytest.mark.parametrize("extra", ["", "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random",
-                                   "--snap_batch 16", "--model RandomTemporalGCN --decomp_type random --snap_batch 5"],
-                         ids=["reference_line", "graphsage", "gat", "random_decomposition", "snap_batch16", "random_snap_batch5"])
+                                   "--snap_batch 16", "--model RandomTemporalGCN --decomp_type random --snap_batch 5",
+                                   "--model TemporalGCN --snap_batch 8"],
+                         ids=["reference_line", "graphsage", "gat", "random_decomposition", "snap_batch16", "random_snap_batch5", "tgcn_snap_batch8"])
 def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra):
     """scripts/RegionalTemporalGCN.sh:1's argument string (copied as a string; --epochs cut to 1) drives the run.py counterpart on
     the TPIMS fixture: epochs + 1 iterations (run.py:230), the run.py:236 line per epoch, a checkpoint with the reference's file
@@ -495,9 +496,12 @@ def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra)
     assert ck.exists()
     sd = torch.load(str(ck), map_location="cpu", weights_only=True)
     n = np.load(os.path.join(GOLDEN, "tpims_fixture.npz"))["node_data"].shape[0]
-    cls = {"RegionalTemporalGCN": R.RegionalTemporalGCN, "RandomTemporalGCN": R.RegionalTemporalGCN, "GraphSAGETemporalGCN": R.GraphSAGETemporalGCN,
-           "GAT": R.GATTemporal}[a.model]
-    cls(8, n, 6, 1).load_state_dict(sd, strict=True)
+    if a.model == "TemporalGCN":
+        R.TemporalGCN(8, 6, 1).load_state_dict(sd, strict=True)
+    else:
+        cls = {"RegionalTemporalGCN": R.RegionalTemporalGCN, "RandomTemporalGCN": R.RegionalTemporalGCN, "GraphSAGETemporalGCN": R.GraphSAGETemporalGCN,
+               "GAT": R.GATTemporal}[a.model]
+        cls(8, n, 6, 1).load_state_dict(sd, strict=True)
     assert all(bool(torch.isfinite(v).all()) for v in sd.values())
 
 
