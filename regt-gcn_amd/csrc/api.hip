@@ -924,9 +924,54 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     if (side_wgrads < 0) { const char* e = getenv("REGT_SIDE_WGRADS"); side_wgrads = e ? atoi(e) : 0; }
     hipStream_t sw = side_wgrads ? side_fork(st) : st;
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
+    // bf16 rows (fused kernels' layout): dUh | dGh = dhp^T [q | A_hat x] and dUzr | dGzr = dzr^T [h | A_hat x] as ONE launch each -- the
+    // A_hat x part is a third column tile of the same row chunk on the same XCD, so dhp / dzp|drp cross HBM once instead of twice.
+    // (Round 3 measured this form slower, 1.86 vs 1.44 ms for the four: every tile issued the loads of BOTH right-hand operands.
+    // Since round 4 a column tile that lies entirely in one operand issues one load, wgrad_split_kernel q_tile.)  REGT_WGRAD_PAIRS=0/1.
+    static int pairs_opt = -1;
+    if (pairs_opt < 0) { const char* e = getenv("REGT_WGRAD_PAIRS"); pairs_opt = e ? atoi(e) : 0; }
+    const bool pairs = pairs_opt && ibf && qbf && abf && xbf && !h_ext && !tcol && C % 128 == 0 && F % 8 == 0 && sw == st;
+    if (pairs) {
+        WgradArgs a{L.dhp, C, C, L.q, C, C + F, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        a.p_bf16 = 1; a.q_bf16 = 1; a.Q2 = L.AX; a.ldq2 = F; a.nin_split = C;
+        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
+        {
+            PROF("wgrad_UhGh", st);
+            TRY(launch_wgrad(a, st));
+        }
+        WgradReduceArgs r{};
+        r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
+        r.elem_offset = 0; r.Nout = C; r.Nin = C; r.out = gr.gate_w[2] + C; r.ldo = 2L * C;
+        r.colsum_out = L.dch; r.colsum_offset = (long)C * (C + F); r.ncolsum = C;
+        TRY(rq.push(r));
+        WgradReduceArgs g{};
+        g.slab = a.slab; g.nchunks = L.nchunks; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
+        g.elem_offset = C; g.Nout = C; g.Nin = F; g.out = L.dGh; g.ldo = F;
+        TRY(rq.push(g));
+    } else {
     TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
     TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
-    if (tcol) {
+    }
+    if (pairs) {
+        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C + F, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        a.p_bf16 = 1; a.q_bf16 = 1; a.Q2 = L.AX; a.ldq2 = F; a.nin_split = C;
+        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
+        {
+            PROF("wgrad_UzrGzr", st);
+            TRY(launch_wgrad(a, st));
+        }
+        for (int k = 0; k < 2; ++k) {
+            WgradReduceArgs r{};
+            r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
+            r.elem_offset = (long)k * C * (C + F); r.Nout = C; r.Nin = C; r.out = gr.gate_w[k] + C; r.ldo = 2L * C;
+            r.colsum_out = k == 0 ? L.dczr : nullptr; r.colsum_offset = 2L * C * (C + F); r.ncolsum = 2 * C;
+            TRY(rq.push(r));
+        }
+        WgradReduceArgs g{};
+        g.slab = a.slab; g.nchunks = L.nchunks; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
+        g.elem_offset = C; g.Nout = 2 * C; g.Nin = F; g.out = L.dGzr; g.ldo = F;
+        TRY(rq.push(g));
+    } else if (tcol) {
         // [dP0 | dP1] = dzr^T [x | L~ x]  (2C x 2F), column sums -> [dcz; dcr]: what is left of dzr^T h (the composition backward
         // below turns it into dUz2 / dUr2 / dW0 / dW1 / db).  One launch with a two-part right-hand side when F is a multiple of
         // the 32-column tile, else one launch per part.
@@ -966,7 +1011,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // (One launch per pair with a two-part right-hand side [q | A_hat x] / [h | A_hat x] -- so that dhp and dzp|drp are read
     // once -- was measured and is slower: 1.86 vs 1.44 ms for the four at the cfg-5 shard; the third, half-empty column tile and
     // the doubled load instructions of the two-descriptor staging cost more than the second pass over the left operand.)
-    TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, sw, ibf, xbf));
+    if (!pairs) TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, sw, ibf, xbf));
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;

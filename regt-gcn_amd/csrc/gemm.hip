@@ -2165,6 +2165,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
     // (an out-of-range lane returns 0 without touching memory) and the two results are OR-ed
     // (bf16-stored Q: the same with the thread's 8-column chunk; nin_split % 8 == 0, host-checked)
     const bool has_q2 = a.Q2 != nullptr;
+    // which operand(s) this column tile reads: 1 = Q only, 2 = Q2 only, 3 = both (the split runs through the tile)
+    const int q_tile = !has_q2 || j0 + 128 <= a.nin_split ? 1 : (j0 >= a.nin_split ? 2 : 3);
     const int qcol = QBF ? j0 + 8 * c8 : j0 + 4 * c4;        // first of the thread's columns of [Q | Q2]
     const bool in_q2 = has_q2 && qcol >= a.nin_split;
     const bool okq = qcol < a.Nin && !in_q2;
@@ -2183,13 +2185,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
         }
         if (QBF) {
             const int m = k0 + 16 * h + (tid >> 4);
-            float4 q = Core::srd_load(sq, live && m < nrows && okq ? 2u * (unsigned)(m * ldq + 8 * c8) : Core::SRD_OOB);
-            if (has_q2) {
-                const float4 q2 = Core::srd_load(sq2, live && m < nrows && okq2 ? 2u * (unsigned)(m * ldq2 + cq2) : Core::SRD_OOB);
-                q.x = __uint_as_float(__float_as_uint(q.x) | __float_as_uint(q2.x));
-                q.y = __uint_as_float(__float_as_uint(q.y) | __float_as_uint(q2.y));
-                q.z = __uint_as_float(__float_as_uint(q.z) | __float_as_uint(q2.z));
-                q.w = __uint_as_float(__float_as_uint(q.w) | __float_as_uint(q2.w));
+            float4 q;
+            if (q_tile == 2) {               // the whole column tile lies in the second operand: ONE load (workgroup-uniform)
+                q = Core::srd_load(sq2, live && m < nrows && okq2 ? 2u * (unsigned)(m * ldq2 + cq2) : Core::SRD_OOB);
+            } else {
+                q = Core::srd_load(sq, live && m < nrows && okq ? 2u * (unsigned)(m * ldq + 8 * c8) : Core::SRD_OOB);
+                if (q_tile == 3) {           // the tile straddles the split: both descriptors, complementary masks
+                    const float4 q2 = Core::srd_load(sq2, live && m < nrows && okq2 ? 2u * (unsigned)(m * ldq2 + cq2) : Core::SRD_OOB);
+                    q.x = __uint_as_float(__float_as_uint(q.x) | __float_as_uint(q2.x));
+                    q.y = __uint_as_float(__float_as_uint(q.y) | __float_as_uint(q2.y));
+                    q.z = __uint_as_float(__float_as_uint(q.z) | __float_as_uint(q2.z));
+                    q.w = __uint_as_float(__float_as_uint(q.w) | __float_as_uint(q2.w));
+                }
             }
             rq[h] = q;
         }
