@@ -858,6 +858,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
 
 // dgrad_candidate with its left operand generated on the way (SplitCore::run_u_gen + EpiDgrad1GenF): cell_bwd_kernel and the candidate
 // data gradient in one launch.  fp32 arithmetic; two workgroups per CU (three operand arrays in flight per A slot).
+template <int NP>     // 0: fp32 MFMA; 3: exact bf16x3 split (REGT_GEMM_MODE=bf16x3) -- fp32 storage either way
 __global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi, int rotate) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, lon
     const long m0 = (long)(bid / tiles_n) * GBM;
     const int n0 = (bid % tiles_n) * GBN;
     RowMap rm{m0, 1, (int)((M - m0) < GBM ? (M - m0) : GBM)};
-    SplitCore<false, 0> core(S, rm, n0, N, lds, true);
+    SplitCore<false, NP> core(S, rm, n0, N, lds, true);
     core.fill_rowtab(epi);
     f32x16 acc[2][2];
 #pragma unroll
@@ -874,7 +875,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, lon
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const SplitCore<false, 0>::AGen g{epi.e.ZR, epi.e.Ht, epi.e.dOH, epi.e.dhp, epi.e.C, (unsigned)epi.e.num_nodes * (unsigned)epi.e.C * 4u};
+    const typename SplitCore<false, NP>::AGen g{epi.e.ZR, epi.e.Ht, epi.e.dOH, epi.e.dhp, epi.e.C, (unsigned)epi.e.num_nodes * (unsigned)epi.e.C * 4u};
     // k walk of this column tile: natural order (rotate = 1, an experiment that lost: start behind the tile's own columns)
     const int nslab = epi.e.C / GBK;
     const int rot = rotate ? ((n0 + GBN) / GBK) % nslab : 0;
@@ -1139,7 +1140,7 @@ int dgrad1_gen_option(int value) {       // regt_set_option("dgrad1_gen", v): re
     return prev;
 }
 bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes) {
-    return dgrad1_gen_wanted() && gemm_mode() == 0 && !fp32_core_wide() && !gemm_desc_table_forced() && C % GBN == 0 && C % GBK == 0 &&
+    return dgrad1_gen_wanted() && (gemm_mode() == 0 || gemm_mode() == 1) && !fp32_core_wide() && !gemm_desc_table_forced() && C % GBN == 0 && C % GBK == 0 &&
            (long)cdiv(M, GBM) * (C / GBN) >= SMALL_TILE_LIMIT && M < (1L << 31) && (long)num_nodes * C * 4 < (1L << 31) &&
            (long)C * 8 * (GBM + 1) < (1L << 31);
 }
@@ -1153,7 +1154,10 @@ int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e,
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
     static int rotate = -1;
     if (rotate < 0) { const char* r = getenv("REGT_DGRAD1_ROT"); rotate = r ? atoi(r) : 0; }
-    hipLaunchKernelGGL(gemm_dgrad1_gen_kernel, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
+    if (gemm_mode() == 1)
+        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<3>, dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
+    else
+        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<0>, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

@@ -383,8 +383,14 @@ struct SplitCore : FastCore<true, REGION> {
             float4 a;
             a.x = cb_dhp(__fmul_rn(p, d.x), z.x, t.x); a.y = cb_dhp(__fmul_rn(p, d.y), z.y, t.y);
             a.z = cb_dhp(__fmul_rn(p, d.z), z.z, t.z); a.w = cb_dhp(__fmul_rn(p, d.w), z.w, t.w);
-            *reinterpret_cast<float4*>(st + off) = a;
-            *reinterpret_cast<float4*>(st + OPER_B + off) = rb[h + 2 * j];
+            if constexpr (NP == 0) {
+                *reinterpret_cast<float4*>(st + off) = a;
+                *reinterpret_cast<float4*>(st + OPER_B + off) = rb[h + 2 * j];
+            } else {                                   // bf16x3: the generated fp32 values are split exactly like loaded ones (store_half)
+                const int offs = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
+                split_store(st + offs, a);
+                split_store(st + OPER_B + offs, rb[h + 2 * j]);
+            }
             buf_st4(s.o, r.vh[j] + ko, 0, a);          // (row + k offset in the VECTOR offset: see the store hazard note in DESIGN 5c.3)
         }
     }
@@ -398,7 +404,7 @@ struct SplitCore : FastCore<true, REGION> {
     // tiles of a row tile then no longer fetch the same slab at the same time and stop sharing their A rows through L2:
     // 10.3 instead of 7.6 GB fetched per launch, 2.73 instead of 2.65 ms; profiles/r04_gen_pmc.txt).
     __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g, int rot) {
-        static_assert(NP == 0, "generated A operand: fp32 core");
+        static_assert(NP == 0 || NP == 3, "generated A operand: fp32 storage (fp32 MFMA or the exact bf16x3 split)");
         nreg_u = 0;
         const int nslab = S.seg[0].K / GBK;
         if (nslab == 0) return;
@@ -455,16 +461,29 @@ struct SplitCore : FastCore<true, REGION> {
         mfmas(f, acc);
         gen_load_half(hs, sn, rows, k_next, q);
         load_b_half(hs, nx, rb);
-        // 32 MFMAs of 64 pipe cycles: the 8 fragment reads up front, then per MFMA gap a share of the generation arithmetic
-        // (~12 VALU per slot), one LDS write or dhp store, later two of the eight global loads
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        if constexpr (NP == 0) {
+            // 32 MFMAs of 64 pipe cycles: the 8 fragment reads up front, then per MFMA gap a share of the generation arithmetic
+            // (~12 VALU per slot), one LDS write or dhp store, later two of the eight global loads
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);   // VALU | SALU
-            if (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        // DS write
-            else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);               // VMEM read
-            if (r >= 2 && r < 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write (dhp)
+            for (int r = 0; r < 8; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);   // VALU | SALU
+                if (r < 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);        // DS write
+                else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);               // VMEM read
+                if (r >= 2 && r < 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write (dhp)
+            }
+        } else {
+            // 24 bf16 MFMAs of 32 cycles: all 12 fragment reads, then per MFMA a share of the generation + split arithmetic
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int r = 0; r < 24; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   // VALU
+                if (r & 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);    // DS write
+                if (r >= 16) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+                if (r >= 6 && r < 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write (dhp)
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -235,7 +235,8 @@ def test_overlapping_regions_take_the_general_layout(R):
     (300, 2000, 2, 8, 150, 1, "regt", 256),         # T = 150 > 128: a node longer than a tile
     (1500, 9000, 3, 8, 12, 1, "regt", 512),         # C = 512: four column tiles, four partial attention dots per row
     (6000, 40000, 3, 8, 12, 1, "regt", 128)])       # C = 128: one column tile (the writer is the only workgroup of a row tile)
-def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, t, o, model, hidden):
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32mfma", "bf16x3split"])
+def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, t, o, model, hidden, mode):
     """fp32 backward with dhp generated inside the candidate data gradient (gemm_dgrad1_gen_kernel: no cell_bwd pass) against the
     two-launch path (regt_set_option("dgrad1_gen", 0)): every gradient that flows through dhp / dzp / drp / dh is BIT-identical
     (same element-wise helpers, same GEMM order); the attention gradient is summed in another fixed order (<= 1e-5 of its scale).
@@ -261,6 +262,7 @@ def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, 
         graph = mod.prepare_graph(ei.cuda(), w.cuda(), n)
     xs = x.cuda()
     res = {}
+    prev_mode = lib.regt_set_gemm_mode(mode)          # the generated-operand kernel exists for both fp32-storage arithmetics
     for gen in (1, 0, 1):
         prev = lib.regt_set_option(b"dgrad1_gen", gen)
         try:
@@ -273,6 +275,7 @@ def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, 
         if gen in res and t <= 64:
             assert all(torch.equal(got[k], res[gen][k]) for k in got)          # the generated path is bit-reproducible
         res[gen] = got
+    lib.regt_set_gemm_mode(prev_mode)
     assert set(res[0]) == set(res[1])
     for k in res[0]:
         if k == "tgnn._attention":
