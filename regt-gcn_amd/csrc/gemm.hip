@@ -201,6 +201,9 @@ struct EpiGatesF {
         }
     }
 };
+// (drp / dh through the fixed instruction sequences cb_drp / cb_dh of kernels.h since round 4: left to -ffp-contract, the two-launch
+// kernel and the generated-operand kernel of the bf16x3 arithmetic contracted `v R + p d Z` differently -- last-bit differences between
+// two paths that tests/test_gpu_ops.py compares bit for bit)
 struct EpiDgrad1F {
     EpiDgrad1 e;
     __device__ __forceinline__ void operator()(long m, int c, float v) const {
@@ -209,8 +212,8 @@ struct EpiDgrad1F {
         float hv = e.h[m * e.C + c];
         float Z = e.ZR[m * (2L * e.C) + c];
         float R = e.ZR[m * (2L * e.C) + e.C + c];
-        e.dzr[m * (2L * e.C) + e.C + c] = v * hv * (R * (1.0f - R));
-        e.dh[m * e.C + c] = v * R + e.probs[t] * e.dOH[node * e.C + c] * Z;
+        e.dzr[m * (2L * e.C) + e.C + c] = cb_drp(v, hv, R);
+        e.dh[m * e.C + c] = cb_dh(v, R, e.probs[t], e.dOH[node * e.C + c], Z);
     }
     static constexpr int ROUND_ROWS = 8;
     struct Aux { float4 h, Z, R, d; float p; };
@@ -225,11 +228,11 @@ struct EpiDgrad1F {
         return a;
     }
     __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
-#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+#define F_(k) cb_drp(v.k, a.h.k, a.R.k)
         if (e.dzr_bf16) st4_bf16(e.dzr, m * (2L * e.C) + e.C + c, REGT_V4(F_));
         else st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
 #undef F_
-#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+#define F_(k) cb_dh(v.k, a.R.k, a.p, a.d.k, a.Z.k)
         st4(e.dh + m * e.C + c, REGT_V4(F_));
 #undef F_
     }
@@ -276,11 +279,11 @@ struct EpiDgrad1F {
         return a;
     }
     template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
-#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+#define F_(k) cb_drp(v.k, a.h.k, a.R.k)
         if (V & 1) buf_st4_bf16(t.dzr, t.vdzr + i * t.sdzr, 0, REGT_V4(F_));
         else buf_st4(t.dzr, t.vdzr + i * t.sdzr, 0, REGT_V4(F_));
 #undef F_
-#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+#define F_(k) cb_dh(v.k, a.R.k, a.p, a.d.k, a.Z.k)
         buf_st4(t.dh, t.vc + i * t.sc, 0, REGT_V4(F_));
 #undef F_
     }
@@ -323,10 +326,10 @@ struct EpiDgrad1GenF {
 #define REGT_GEN_DOT(a) ((a.d.x * (a.Z.x * a.h.x + (1.0f - a.Z.x) * a.t.x) + a.d.y * (a.Z.y * a.h.y + (1.0f - a.Z.y) * a.t.y)) + \
                          (a.d.z * (a.Z.z * a.h.z + (1.0f - a.Z.z) * a.t.z) + a.d.w * (a.Z.w * a.h.w + (1.0f - a.Z.w) * a.t.w)))
     __device__ __forceinline__ void apply(long m, int c, float4 v, const Aux& a) const {
-#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+#define F_(k) cb_drp(v.k, a.h.k, a.R.k)
         st4(e.dzr + m * (2L * e.C) + e.C + c, REGT_V4(F_));
 #undef F_
-#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+#define F_(k) cb_dh(v.k, a.R.k, a.p, a.d.k, a.Z.k)
         st4(e.dh + m * e.C + c, REGT_V4(F_));
 #undef F_
 #define F_(k) cb_dzp(__fmul_rn(a.p, a.d.k), a.h.k, a.t.k, a.Z.k)
@@ -379,10 +382,10 @@ struct EpiDgrad1GenF {
         return a;
     }
     template <int V> __device__ __forceinline__ void vapply(const Tile& t, int i, float4 v, const Col&, const VAux& a) const {
-#define F_(k) (v.k * a.h.k * (a.R.k * (1.0f - a.R.k)))
+#define F_(k) cb_drp(v.k, a.h.k, a.R.k)
         buf_st4(t.dzr, t.vzr + i * t.szr + e.C * 4, 0, REGT_V4(F_));
 #undef F_
-#define F_(k) (v.k * a.R.k + a.p * a.d.k * a.Z.k)
+#define F_(k) cb_dh(v.k, a.R.k, a.p, a.d.k, a.Z.k)
         buf_st4(t.dh, t.vc + i * t.sc, 0, REGT_V4(F_));
 #undef F_
 #define F_(k) cb_dzp(__fmul_rn(a.p, a.d.k), a.h.k, a.t.k, a.Z.k)
