@@ -210,12 +210,20 @@ class AttentionPattern:
     t_col: torch.Tensor
 
 
-def prepare_mean_operator(edge_index: torch.Tensor, num_nodes: int) -> MeanOperator:
+def prepare_mean_operator(edge_index: torch.Tensor, num_nodes: int, copies: int = 1) -> MeanOperator:
+    """``copies`` > 1: the block-diagonal operator of that many disjoint copies of the graph (snapshot batching: the mean over a
+    node's in-neighbours is local to its copy)."""
+    if copies > 1:
+        edge_index, _ = replicate_edges(edge_index, None, copies, num_nodes)
+        num_nodes *= copies
     rp, col, val = mean_csr(edge_index, num_nodes)
     return MeanOperator(num_nodes, rp, col, val)
 
 
-def prepare_attention_pattern(edge_index: torch.Tensor, num_nodes: int) -> AttentionPattern:
+def prepare_attention_pattern(edge_index: torch.Tensor, num_nodes: int, copies: int = 1) -> AttentionPattern:
+    if copies > 1:      # (the attention softmax runs over a node's in-neighbours: local to its copy)
+        edge_index, _ = replicate_edges(edge_index, None, copies, num_nodes)
+        num_nodes *= copies
     rp, col, val = gcn_csr(edge_index, None, num_nodes)          # the pattern of gcn_norm = remove + add self loops
     t = transpose_csr(rp, col, val, num_nodes, num_nodes)
     return AttentionPattern(num_nodes, rp, col, t[0], t[1])
@@ -311,7 +319,10 @@ def transpose_csr(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, nu
     return t_rowptr.contiguous(), t_col.contiguous(), t_val
 
 
-def prepare_gcn_operator(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int) -> GcnOperator:
+def prepare_gcn_operator(edge_index: torch.Tensor, edge_weight: Optional[torch.Tensor], num_nodes: int, copies: int = 1) -> GcnOperator:
+    if copies > 1:
+        edge_index, edge_weight = replicate_edges(edge_index, edge_weight, copies, num_nodes)
+        num_nodes *= copies
     rp, col, val = gcn_csr(edge_index, edge_weight, num_nodes)
     t = transpose_csr(rp, col, val, num_nodes, num_nodes)
     return GcnOperator(num_nodes, rp, col, val, t[0], t[1], t[2])

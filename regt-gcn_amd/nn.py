@@ -364,8 +364,8 @@ class ConvStackedTemporalGCN(nn.Module):
         self.output_dim = output_dim
         self._graphs = _GraphCache()
 
-    def prepare_graph(self, edge_index, edge_attr, num_nodes: int) -> GcnOperator:
-        return prepare_gcn_operator(edge_index, edge_attr, num_nodes)
+    def prepare_graph(self, edge_index, edge_attr, num_nodes: int, copies: int = 1) -> GcnOperator:
+        return prepare_gcn_operator(edge_index, edge_attr, num_nodes, copies)
 
     # conv1 .. conv5 are applied WITHOUT an activation in between (models/ConvStackedTemporalGCN.py:116-120), and the aggregation
     # (acts on the node axis) commutes with the linear maps (act on the feature axis), so the five layers collapse exactly:
@@ -517,8 +517,8 @@ class GraphSAGETemporalGCN(_ZeroHiddenModel):
         self.relu = nn.ReLU()
         self._graphs = _GraphCache()
 
-    def prepare_graph(self, edge_index, num_nodes: int) -> MeanOperator:
-        return prepare_mean_operator(edge_index, num_nodes)
+    def prepare_graph(self, edge_index, num_nodes: int, copies: int = 1) -> MeanOperator:
+        return prepare_mean_operator(edge_index, num_nodes, copies)
 
     def forward_prepared(self, x: torch.Tensor, op: MeanOperator):
         _need_cuda(x)
@@ -559,8 +559,8 @@ class GATTemporal(_ZeroHiddenModel):
         self.relu = nn.ReLU()
         self._graphs = _GraphCache()
 
-    def prepare_graph(self, edge_index, num_nodes: int) -> AttentionPattern:
-        return prepare_attention_pattern(edge_index, num_nodes)
+    def prepare_graph(self, edge_index, num_nodes: int, copies: int = 1) -> AttentionPattern:
+        return prepare_attention_pattern(edge_index, num_nodes, copies)
 
     def forward_prepared(self, x: torch.Tensor, pat: AttentionPattern):
         _need_cuda(x)

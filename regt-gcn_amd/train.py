@@ -305,12 +305,14 @@ def main(argv=None):
         log = open(os.path.join("logs", datetime.datetime.now().strftime("%y-%m-%d_%H-%M") + ".txt"), "a")
     batched = None
     if a.snap_batch > 1:
-        if a.model not in ("RegionalTemporalGCN", "RandomTemporalGCN", "TemporalGCN"):
-            raise SystemExit("--snap_batch covers RegionalTemporalGCN / RandomTemporalGCN / TemporalGCN")
         if a.fused_step:
             raise SystemExit("--snap_batch and --fused_step are alternatives (both remove per-snapshot host work)")
-        if a.model == "TemporalGCN":
+        # every operator of these models is local to a node's in-neighbours (gcn_norm, ChebConv.__norm__, SAGE mean, GAT softmax), so
+        # B disjoint copies of the graph are B independent snapshots
+        if a.model in ("TemporalGCN", "ConvStackedTemporalGCN"):
             graphs = BatchedGraphs(lambda b: model.prepare_graph(ei, ea, n, copies=b))
+        elif a.model in ("GraphSAGETemporalGCN", "GAT", "GATTemporal"):
+            graphs = BatchedGraphs(lambda b: model.prepare_graph(ei, n, copies=b))
         else:
             graphs = BatchedGraphs(lambda b: model.prepare_graph(ei, r_idx, r_att, copies=b))
         batched = (WindowStore(tx, ty), WindowStore(vx, vy), graphs)

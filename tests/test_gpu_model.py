@@ -479,8 +479,9 @@ print("OK", list(st))
 
 @pytest.mark.parametrize("extra", ["", "--model GraphSAGETemporalGCN", "--model GAT", "--model RandomTemporalGCN --decomp_type random",
                                    "--snap_batch 16", "--model RandomTemporalGCN --decomp_type random --snap_batch 5",
-                                   "--model TemporalGCN --snap_batch 8"],
-                         ids=["reference_line", "graphsage", "gat", "random_decomposition", "snap_batch16", "random_snap_batch5", "tgcn_snap_batch8"])
+                                   "--model TemporalGCN --snap_batch 8", "--model GraphSAGETemporalGCN --snap_batch 4", "--model GAT --snap_batch 4"],
+                         ids=["reference_line", "graphsage", "gat", "random_decomposition", "snap_batch16", "random_snap_batch5", "tgcn_snap_batch8",
+                              "graphsage_snap_batch4", "gat_snap_batch4"])
 def test_reference_launch_line_trains_on_the_fixture(R, tmp_path, capsys, extra):
     """scripts/RegionalTemporalGCN.sh:1's argument string (copied as a string; --epochs cut to 1) drives the run.py counterpart on
     the TPIMS fixture: epochs + 1 iterations (run.py:230), the run.py:236 line per epoch, a checkpoint with the reference's file

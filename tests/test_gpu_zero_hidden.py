@@ -152,3 +152,47 @@ def test_dead_reset_gate_gets_zero_gradients_from_either_output(R, name):
     assert g is not None and float(g.abs().max()) == 0.0
     gh = dict(mod.named_parameters())["linear1.weight"].grad                    # the head is not on hidden's path: no gradient, or
     assert gh is None or float(gh.abs().max()) == 0.0                           # (an autograd Function materialises it) zeros
+
+
+@pytest.mark.parametrize("name", ["GraphSAGETemporalGCN", "GATTemporal", "ConvStackedTemporalGCN"])
+def test_snapshot_batch_of_the_other_models_equals_per_snapshot_runs(R, name):
+    """--snap_batch for the models whose operators are not the RegT-GCN ones: SAGE's mean, GAT's softmax over in-neighbours and the
+    stacked GCNConv are all local to a node's in-neighbours, so B disjoint copies of the graph (prepare_graph(copies=B)) are B
+    independent snapshots: predictions of every copy and the summed gradients equal the per-snapshot runs."""
+    n, e, f, t, o, b = 300, 2500, 8, 6, 2, 3
+    ei = _graph(n, e, 77)
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.rand(n, f, t, generator=gen) for _ in range(b)]
+    ys = [torch.rand(n, o, generator=gen) for _ in range(b)]
+    if name == "ConvStackedTemporalGCN":
+        p = M.init_params(name, f, t, o, seed=5)
+        for layer in range(2, 6):
+            p[f"tgnn.conv{layer}.lin.weight"] *= 0.5
+        mod = R.ConvStackedTemporalGCN(f, t, o)
+        w = (torch.rand(ei.shape[1], generator=gen) * 100 + 1).cuda()
+        prep = lambda copies: mod.prepare_graph(ei.cuda(), w, n, copies=copies)
+    else:
+        p = M.init_params(name, f, t, o, num_nodes=n, seed=5)
+        mod = getattr(R, name)(node_features=f, num_nodes=n, periods=t, output_dim=o)
+        prep = lambda copies: mod.prepare_graph(ei.cuda(), n, copies=copies)
+    mod.load_state_dict(p, strict=True)
+    mod = mod.cuda()
+    g1, gb = prep(1), prep(b)
+    preds = []
+    for x, y in zip(xs, ys):
+        pred, _ = mod.forward_prepared(x.cuda(), g1)
+        (((pred - y.cuda()) ** 2).sum() / (n * o)).backward()
+        preds.append(pred.detach())
+    want = {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}
+    mod.zero_grad(set_to_none=True)
+    xb, yb = torch.cat(xs).cuda(), torch.cat(ys).cuda()
+    pred, _ = mod.forward_prepared(xb, gb)
+    (((pred - yb) ** 2).sum() / (n * o)).backward()
+    scale = max(1.0, float(pred.abs().max()))
+    for i in range(b):
+        assert float((pred[i * n:(i + 1) * n].detach() - preds[i]).abs().max()) < 2e-5 * scale
+    for k, q in mod.named_parameters():
+        if k not in want:
+            assert q.grad is None, k
+            continue
+        np.testing.assert_allclose(q.grad.cpu().numpy(), want[k].cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, float(want[k].abs().max())), err_msg=k)
