@@ -388,6 +388,10 @@ struct SplitCore : FastCore<true, REGION> {
                 *reinterpret_cast<float4*>(st + OPER_B + off) = rb[h + 2 * j];
             } else {                                   // bf16x3: the generated fp32 values are split exactly like loaded ones (store_half)
                 const int offs = sp_off((tid >> 2) + 64 * j, (tid >> 1) & 1) + (tid & 1) * 8;
+                // (opaque to the optimiser: left alone, hipcc contracts cb_dhp's last multiply with the split's first subtraction
+                // -- fma(t1, t2, -piece1) -- so planes 2 and 3 held the residual of the UNROUNDED product while plane 1 and the
+                // stored dhp hold the rounded one: 1e-7 away from the two-launch path, found by tests/test_gpu_ops.py)
+                asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w));
                 split_store(st + offs, a);
                 split_store(st + OPER_B + offs, rb[h + 2 * j]);
             }

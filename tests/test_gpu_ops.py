@@ -285,10 +285,6 @@ def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, 
             # (a node of more than 64 rows meets three or more partial sums in the forward's hidden state: not bit-reproducible
             # between ANY two runs, include/regtgcn.h -- the two backward paths then see different dOH in the last bits)
             assert float((res[0][k] - res[1][k]).abs().max()) <= 1e-5 * max(float(res[0][k].abs().max()), 1e-12), k
-        elif mode == 1:
-            # bf16x3: the z- and h-gate gradients (dzp, dhp) are bit-identical, the r-gate and embedding gradients (through drp / dh)
-            # agree to the last bits only -- measured 1e-7 of scale; which step of the split GEMM's epilogue differs was not isolated
-            assert float((res[0][k] - res[1][k]).abs().max()) <= 1e-6 * max(float(res[0][k].abs().max()), 1e-12), k
         else:
             assert torch.equal(res[0][k], res[1][k]), k
 
