@@ -88,6 +88,7 @@ def main(argv=None):
     ap.add_argument("--num_timesteps_in", default=6, type=int)
     ap.add_argument("--num_timesteps_out", default=1, type=int)
     ap.add_argument("--tr", "--train_ratio", default=0.2, type=float, dest="tr")
+    ap.add_argument("--snap_batch", type=int, default=1, help="test snapshots per forward (block-diagonal graph of B copies; same metrics)")
     a = ap.parse_args(argv)
     if a.pickle:
         d = load_processed_pickle(a.pickle)
@@ -108,7 +109,16 @@ def main(argv=None):
         model = rnn.TemporalGCN(f, a.num_timesteps_in, a.num_timesteps_out).to(dev)
         graph = model.prepare_graph(d["edge_index"].to(dev), d["edge_attr"].to(dev), n)
     model.load_state_dict(torch.load(a.checkpoint, map_location=dev, weights_only=True))
-    mae, rmse, mape = predict_metrics(model, vx, vy, graph)
+    if a.snap_batch > 1:
+        from .train import BatchedGraphs, WindowStore
+        if a.model == "RegionalTemporalGCN":
+            idx, att = [d[f"edge_{r}_index"].to(dev) for r in REGIONS], [d[f"edge_{r}_attr"].to(dev) for r in REGIONS]
+            graphs = BatchedGraphs(lambda b: model.prepare_graph(d["edge_index"].to(dev), idx, att, copies=b))
+        else:
+            graphs = BatchedGraphs(lambda b: model.prepare_graph(d["edge_index"].to(dev), d["edge_attr"].to(dev), n, copies=b))
+        mae, rmse, mape = predict_metrics_batched(model, WindowStore(vx, vy), graphs, a.snap_batch)
+    else:
+        mae, rmse, mape = predict_metrics(model, vx, vy, graph)
     print("MAE: {:.4f}, RMSE: {:.4f}, MAPE: {:.4f}".format(mae, rmse, mape))
 
 
