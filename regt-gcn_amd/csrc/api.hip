@@ -197,6 +197,11 @@ enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4, FMT_TCOLLAPSE = 8 };
 // ever fed weight gradients of that linear map) and the (2C x C) weight gradient dzr^T h become (2C x F) contractions on x and L~ x
 // plus tiny compositions.  h itself is still formed: the reset gate multiplies it (q = h * R) and the blend reads it.
 // REGT_TGCN_COLLAPSE=0 / regt_set_option("tgcn_collapse", 0): the uncollapsed form (A/B, tests).
+int g_opt_wgrad_pairs = -1;
+int wgrad_pairs_setting() {
+    if (g_opt_wgrad_pairs < 0) { const char* e = getenv("REGT_WGRAD_PAIRS"); g_opt_wgrad_pairs = e ? (atoi(e) ? 1 : 0) : 2; }
+    return g_opt_wgrad_pairs;
+}
 int g_opt_tcollapse = -1;
 bool tcollapse_wanted() {
     if (g_opt_tcollapse < 0) { const char* e = getenv("REGT_TGCN_COLLAPSE"); g_opt_tcollapse = e ? atoi(e) : 1; }
@@ -928,9 +933,10 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // A_hat x part is a third column tile of the same row chunk on the same XCD, so dhp / dzp|drp cross HBM once instead of twice.
     // (Round 3 measured this form slower, 1.86 vs 1.44 ms for the four: every tile issued the loads of BOTH right-hand operands.
     // Since round 4 a column tile that lies entirely in one operand issues one load, wgrad_split_kernel q_tile.)  REGT_WGRAD_PAIRS=0/1.
-    static int pairs_opt = -1;
-    if (pairs_opt < 0) { const char* e = getenv("REGT_WGRAD_PAIRS"); pairs_opt = e ? atoi(e) : 0; }
-    const bool pairs = pairs_opt && ibf && qbf && abf && xbf && !h_ext && !tcol && C % 128 == 0 && F % 8 == 0 && sw == st;
+    // With the ring kernel (round 4) the paired form wins (0.64 + 0.43 against 0.54 + 0.35 + 0.29 + 0.18 ms at the cfg-5 shard) and is
+    // the default whenever that kernel is on; REGT_WGRAD_PAIRS / regt_set_option("wgrad_pairs", 0 | 1 | 2 = follow the ring kernel).
+    const int pairs_opt = wgrad_pairs_setting();
+    const bool pairs = (pairs_opt == 2 ? wgrad_ring_active() : pairs_opt == 1) && ibf && qbf && abf && xbf && !h_ext && !tcol && C % 128 == 0 && F % 8 == 0 && sw == st;
     if (pairs) {
         WgradArgs a{L.dhp, C, C, L.q, C, C + F, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
         a.p_bf16 = 1; a.q_bf16 = 1; a.Q2 = L.AX; a.ldq2 = F; a.nin_split = C;
@@ -1165,6 +1171,9 @@ int32_t regt_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);
+    if (!strcmp(name, "wgrad_ring")) return wgrad_ring_option(value);
+    if (!strcmp(name, "wgrad_tile")) return wgrad_tile_option(value);
+    if (!strcmp(name, "wgrad_pairs")) { const int prev = wgrad_pairs_setting(); g_opt_wgrad_pairs = value < 0 || value > 2 ? 2 : value; return prev; }
     if (!strcmp(name, "tgcn_collapse")) { const int prev = tcollapse_wanted() ? 1 : 0; g_opt_tcollapse = value ? 1 : 0; return prev; }
     set_error("regt_set_option: unknown option '%s'", name);
     return -1;

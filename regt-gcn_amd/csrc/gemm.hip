@@ -1137,6 +1137,29 @@ static bool dgrad1_gen_wanted() {
     if (g_dgrad1_gen < 0) { const char* e = getenv("REGT_DGRAD1_GEN"); g_dgrad1_gen = e ? atoi(e) : 1; }
     return g_dgrad1_gen != 0;
 }
+// Depth of the register ring of wgrad_bf16_ring_kernel: REGT_WGRAD_RING / regt_set_option("wgrad_ring", d) = 0 (the one-half-slab-
+// ahead kernel wgrad_split_kernel<1, true, true>: same slabs bit for bit) | 4 | 6 | 8 half slabs of lead.
+static int g_wgrad_ring = -1;
+static int wgrad_ring_depth() {
+    if (g_wgrad_ring < 0) { const char* e = getenv("REGT_WGRAD_RING"); g_wgrad_ring = e ? atoi(e) : 6; }
+    return g_wgrad_ring;
+}
+static int g_wgrad_tile = -1;
+static int wgrad_tile_rows() {
+    if (g_wgrad_tile < 0) { const char* e = getenv("REGT_WGRAD_TILE"); g_wgrad_tile = e && atoi(e) == 128 ? 128 : 256; }
+    return g_wgrad_tile;
+}
+int wgrad_tile_option(int value) {
+    const int prev = wgrad_tile_rows();
+    g_wgrad_tile = value == 256 ? 256 : 128;
+    return prev;
+}
+bool wgrad_ring_active() { return wgrad_ring_depth() > 0; }
+int wgrad_ring_option(int value) {
+    const int prev = wgrad_ring_depth();
+    g_wgrad_ring = value < 0 ? 0 : value;
+    return prev;
+}
 int dgrad1_gen_option(int value) {       // regt_set_option("dgrad1_gen", v): returns the previous setting
     const int prev = dgrad1_gen_wanted() ? 1 : 0;
     g_dgrad1_gen = value ? 1 : 0;
@@ -2377,6 +2400,227 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradArgs a) {
     }
 }
 
+// ---- both operands STORED as bf16 (the bf16-row layout of the cfg-5 path): deep register ring --------------------------------
+// Same tile, chunking, LDS image, MFMA and summation order as wgrad_split_kernel<1, true, true> (bit-identical slabs), but the rows
+// are requested D half slabs ahead instead of one: a half slab of both operands is 8 KB per workgroup and the K loop consumes one per
+// ~0.1 us, so with one half slab of lead every step waited out a full memory latency (wait_any 0.64, 4.1 TB/s).  D half slabs of
+// lead keep D x 8 KB per workgroup in flight (Little: 8 TB/s x ~2 us / 256 CUs = 64 KB per CU).  The ring lives in registers
+// (two float4 per slot), statically indexed: the K loop is unrolled D times.  A two-part right-hand side [Q | Q2] is taken when the
+// split falls on a column-tile boundary (the tile reads one of the two).
+// MI = 32-row MFMA tiles of a wave along the output rows: 2 = the 128 x 128 tile of wgrad_split_kernel; 4 = a 256 x 128 tile (the
+// left operand's half slab is two 128-column images, wave row wr reads image wr): a column tile's rows of P cross L2 -> LDS once per
+// 256 instead of once per 128 output rows (the paired gradients dhp^T [q | A_hat x], dzr^T [h | A_hat x]: 1088 / 2176 instead of
+// 1536 / 3072 operand elements per row and chunk), twice the MFMA work per barrier.  Every output element still sums the same
+// products in the same order: the slabs do not depend on MI.
+template <int D, int MI>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_ring_kernel(WgradArgs a) {
+    static_assert(D >= 2 && D % 2 == 0, "ring depth: even (the LDS stage of a slot is static)");
+    static_assert(MI == 2 || MI == 4, "128- or 256-row tile");
+    constexpr int NPL = MI / 2;                          // 128-column images of P per half slab
+    constexpr int TI = 64 * MI;                          // output rows of a tile
+    constexpr int WS_Q_B = NPL * WS_PLANE_B, WS_STAGE_B = (NPL + 1) * WS_PLANE_B;
+    using Core = FastCore<true, false>;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char* ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int tiles_i = (a.Nout + TI - 1) / TI, tiles_j = (a.Nin + 127) / 128;
+    const int tpc = tiles_i * tiles_j;
+    int tile, chunk;
+    {   // all tiles of one row chunk on the same XCD (see wgrad_kernel)
+        const int nfull = (a.nchunks / 8) * 8;
+        const int b = blockIdx.x;
+        if (b < nfull * tpc) {
+            const int xcd = b & 7, li = b >> 3;
+            chunk = (li / tpc) * 8 + xcd;
+            tile = li % tpc;
+        } else {
+            const int r = b - nfull * tpc;
+            chunk = nfull + r / tpc;
+            tile = r % tpc;
+        }
+    }
+    const int i0 = (tile / tiles_j) * TI, j0 = (tile % tiles_j) * 128;
+    long r0, r1;
+    if (a.chunk_tab) { r0 = a.chunk_tab[2 * chunk]; r1 = a.chunk_tab[2 * chunk + 1]; }
+    else { r0 = (long)chunk * a.kchunk; r1 = r0 + a.kchunk < a.M ? r0 + a.kchunk : a.M; }
+    const int nrows = (int)(r1 - r0);
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 csum[NPL][2];                                 // column sums of the thread's 8 columns of each image over its rows
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) csum[pl][0] = csum[pl][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool do_csum = a.colsum && j0 == 0;
+
+    const bool second = a.Q2 != nullptr && j0 >= a.nin_split;        // workgroup-uniform: this column tile lies in Q2
+    const int ldp = (int)a.ldp, ldq = second ? (int)a.ldq2 : (int)a.ldq;
+    // Descriptors that END with the chunk's last row: a row past the chunk is out of range by itself (the hardware returns zeros
+    // without touching memory), so the K loop carries no row test -- one running byte offset per operand.  A thread whose columns
+    // lie outside the matrix starts at 2^31: beyond every range the host admits (chunk rows x row bytes < 2^31), and the walk
+    // ((rows + 32 + 16 D) x row bytes) cannot wrap it back into range.
+    auto chunk_srd = [](const char* base, unsigned bytes) {
+        const unsigned long long v = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t sp = chunk_srd(reinterpret_cast<const char*>(a.P) + 2 * (r0 * a.ldp + i0), 2u * (unsigned)nrows * (unsigned)ldp);
+    const __amdgpu_buffer_rsrc_t sq = chunk_srd(second ? reinterpret_cast<const char*>(a.Q2) + 2 * (r0 * a.ldq2 + (j0 - a.nin_split))
+                                                       : reinterpret_cast<const char*>(a.Q) + 2 * (r0 * a.ldq + j0), 2u * (unsigned)nrows * (unsigned)ldq);
+    const int c8 = tid & 15, mrow = tid >> 4;            // the thread's 16-byte chunk (8 columns) and row of a half slab
+    constexpr unsigned MASKED = 0x80000000u;
+    // (MI = 4 is launched for Nout % 256 == 0 only: both images of P lie inside the matrix)
+    unsigned vp = i0 + 8 * c8 < a.Nout ? 2u * (unsigned)(mrow * ldp + 8 * c8) : MASKED;      // running byte offsets: half slab g
+    unsigned vq = j0 + 8 * c8 < a.Nin ? 2u * (unsigned)(mrow * ldq + 8 * c8) : MASKED;
+    const unsigned stepp = 32u * (unsigned)ldp, stepq = 32u * (unsigned)ldq;                   // bytes per half slab (16 rows)
+
+    float4 rp[D][NPL], rq[D];
+    auto load = [&](int slot) {                          // the NEXT half slab of the chunk (requests are issued in row order)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) rp[slot][pl] = Core::srd_load(sp, vp + 256u * pl);
+        rq[slot] = Core::srd_load(sq, vq);
+        vp += stepp;
+        vq += stepq;
+        asm volatile("" : "+v"(vp), "+v"(vq));           // ONE running offset per operand (not one per unrolled slot)
+    };
+    const int lds_w = ws_off(mrow, c8);
+    struct Frags { bf16x8 a[MI], b[2]; };
+    const int gq = (lane >> 2) & 3, gp = lane & 3, gg = lane >> 4;
+    auto read_frags = [&](int stage) {
+        const char* st = ldsb + stage * WS_STAGE_B;
+        Frags f;
+        const int sub = 8 * (gp & 1);
+        const int m0 = 8 * (gg >> 1) + gq;
+#pragma unroll
+        for (int t = 0; t < MI; ++t) {
+            const int col = wr * (32 * MI) + t * 32;         // first column of the wave's tile t in the 64 MI-column left operand
+            const int ca = ((col & 127) + 16 * (gg & 1) + 4 * gp) >> 3;
+            const char* pl = st + (col >> 7) * WS_PLANE_B;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl + ws_off(m0, ca) + sub));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pl + ws_off(m0 + 4, ca) + sub));
+            f.a[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int cb = (wc * 64 + t * 32 + 16 * (gg & 1) + 4 * gp) >> 3;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + WS_Q_B + ws_off(m0, cb) + sub));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + WS_Q_B + ws_off(m0 + 4, cb) + sub));
+            f.b[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+        return f;
+    };
+    auto mfmas = [&](const Frags& f, int half) {             // half 0 / 1: the first / last MI / 2 row tiles
+#pragma unroll
+        for (int m = 0; m < MI / 2; ++m)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int mi = half * (MI / 2) + m;
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[mi], f.b[ni], acc[mi][ni], 0, 0, 0);
+            }
+    };
+
+    const int G = 2 * ((nrows + 31) / 32);               // half slabs, the last one possibly all zero (as wgrad_split_kernel walks them)
+    // The K loop exists twice: with the column sums of P (the workgroups of column tile 0 when a bias gradient is asked for) and
+    // without -- 12 of a step's ~30 vector instructions, and the loop is bound by instruction issue once the ring hides the latency.
+    auto k_loop = [&](auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
+        auto store = [&](int slot, int stage) {
+            char* st = ldsb + stage * WS_STAGE_B;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const float4 raw = rp[slot][pl];
+                *reinterpret_cast<float4*>(st + pl * WS_PLANE_B + lds_w) = raw;
+                if (CS) {
+                    const float4 lo = widen_bf16x4(__float_as_uint(raw.x), __float_as_uint(raw.y));
+                    const float4 hi = widen_bf16x4(__float_as_uint(raw.z), __float_as_uint(raw.w));
+                    float4& c0 = csum[pl][0];
+                    float4& c1 = csum[pl][1];
+                    c0.x += lo.x; c0.y += lo.y; c0.z += lo.z; c0.w += lo.w;
+                    c1.x += hi.x; c1.y += hi.y; c1.z += hi.z; c1.w += hi.w;
+                    // pins the sums to this place (instruction selection otherwise sinks the whole chain to the end of the unrolled
+                    // turn, keeping every slot's old rows alive past its reload)
+                    asm volatile("" : "+v"(c0.x), "+v"(c0.y), "+v"(c0.z), "+v"(c0.w), "+v"(c1.x), "+v"(c1.y), "+v"(c1.z), "+v"(c1.w));
+                }
+            }
+            *reinterpret_cast<float4*>(st + WS_Q_B + lds_w) = rq[slot];
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) load(u);
+        store(0, 0);
+        load(0);
+        // step g: multiply half slab g (stage g & 1) while half slab g + 1 goes to the other stage and g + 1 + D is requested
+        auto step = [&](int u) {
+            const int sn = (u + 1) % D;
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            const Frags f = read_frags(u & 1);
+            store(sn, (u + 1) & 1);
+            mfmas(f, 0);
+            // the slot's old contents are consumed (LDS write, column sums) before it is requested again: if the scheduler lets the two
+            // live ranges overlap, the new rows land in other registers and are COPIED into the slot at the loop's back edge -- behind a
+            // wait for the whole ring
+            __builtin_amdgcn_sched_barrier(0);
+            load(sn);
+            mfmas(f, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // whole turns of the ring as ONE basic block (a test per step gives every step a second predecessor, and the wait-count
+        // insertion then assumes the slot's loads are the youngest: vmcnt(0) before every store); the last G % D steps test
+        int gb = 0;
+        for (; gb + D <= G; gb += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) step(u);
+        }
+#pragma unroll
+        for (int u = 0; u < D - 1; ++u)
+            if (gb + u < G) step(u);
+    };
+    if (G > 0) {
+        if (do_csum || a.all_csum) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
+    }
+    const long stride = (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0);
+    float* out = a.slab + (long)chunk * stride;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int i = i0 + wr * (32 * MI) + mi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            if (i < a.Nout) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int j = j0 + wc * 64 + ni * 32 + lr;
+                    if (j < a.Nin) out[(long)i * a.Nin + j] = acc[mi][ni][reg];
+                }
+            }
+        }
+    if (do_csum) {       // 16 threads (tid >> 4) hold partial sums of the same 8 columns of an image: fixed-order sum through LDS
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            reinterpret_cast<float4*>(lds)[512 * pl + 2 * tid] = csum[pl][0];
+            reinterpret_cast<float4*>(lds)[512 * pl + 2 * tid + 1] = csum[pl][1];
+        }
+        __syncthreads();
+        if (tid < 128 * NPL && i0 + tid < a.Nout) {
+            const int pl = tid >> 7, c = tid & 127;
+            float s = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s += lds[2048 * pl + (g * 16 + (c >> 3)) * 8 + (c & 7)];
+            out[(long)a.Nout * a.Nin + i0 + tid] = s;
+        }
+    }
+}
+
 // Generic fallback (scalar-guarded loads) for operands that are not 16-byte tileable, e.g. the (N, O) head gradient.
 template <int BNW>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
 __global__ __launch_bounds__(256, 2) void wgrad_kernel_generic(WgradArgs a) {
@@ -2526,7 +2770,40 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
             REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16) || (a.Nout % 8 == 0 && a.Nin % 8 == 0 && a.ldp % 8 == 0 && a.ldq % 8 == 0 && !a.q_relu),
                            "wgrad: bf16-stored operands need 8-element aligned rows");
             const size_t lb = 4 * 1 * WS_PLANE_B;
-            if (a.p_bf16 && a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
+            const int ring = wgrad_ring_depth();
+            // (the ring kernel's descriptors end with the chunk: chunk rows x row bytes must stay below 2^31)
+            const long ld_max = std::max(a.ldp, std::max(a.ldq, a.Q2 ? a.ldq2 : 0L));
+            const long rows_max = a.chunk_tab ? a.M : (long)a.kchunk + 32;
+            const bool ring_ok = a.p_bf16 && a.q_bf16 && ring > 0 && (!a.Q2 || a.nin_split % 128 == 0) && 2 * rows_max * ld_max < (1L << 31);
+            // 256-row tiles where the output has them (regt_set_option("wgrad_tile", 128 | 256) / REGT_WGRAD_TILE); ring of 4 there
+            // (6 half slabs of three 16-byte loads spill)
+            // experiment: REGT_WGRAD_OCC = 1 | 2 pads the dynamic LDS so that only that many workgroups share a CU
+            // Every column tile forms the column sums of P although only tile 0 stores them (REGT_WGRAD_SYM=0: tile 0 alone): the
+            // tiles of a row chunk share P (and Q between row tiles) through their XCD's L2 and only find each other's lines there
+            // while they walk the chunk in step -- with a third less vector work the other tiles run ahead and every tile reads its
+            // operands from HBM (measured: 0.90 / 0.51 ms against 0.71 / 0.45 ms for the two paired gradients of the cfg-5 shard).
+            static int sym = -1;
+            if (sym < 0) { const char* e = getenv("REGT_WGRAD_SYM"); sym = e ? atoi(e) : 1; }
+            WgradArgs am = a;
+            am.all_csum = sym && a.colsum;
+            static int occ = -1;
+            if (occ < 0) { const char* e = getenv("REGT_WGRAD_OCC"); occ = e ? atoi(e) : 0; }
+            auto padded = [&](size_t need) { return occ > 0 ? std::max(need, (size_t)(160 * 1024 / occ - 1024)) : need; };
+            auto launch_ring = [&](auto kernel, long nblocks, size_t need) -> int {
+                static bool attr_done_r = false;
+                const size_t bytes = padded(need);
+                if (bytes > 48 * 1024) { if (int rc = set_lds_once(kernel, (int)bytes, &attr_done_r)) return rc; }
+                hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(256), bytes, st, am);
+                return REGT_OK;
+            };
+            if (ring_ok && wgrad_tile_rows() == 256 && a.Nout % 256 == 0) {
+                const long blocks4 = (long)(a.Nout / 256) * cdiv(a.Nin, 128) * a.nchunks;
+                if (int rc = launch_ring(&wgrad_bf16_ring_kernel<4, 4>, blocks4, 2 * 3 * WS_PLANE_B)) return rc;
+            }
+            else if (ring_ok && ring >= 8) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<8, 2>, blocks, lb)) return rc; }
+            else if (ring_ok && ring >= 6) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<6, 2>, blocks, lb)) return rc; }
+            else if (ring_ok) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<4, 2>, blocks, lb)) return rc; }
+            else if (a.p_bf16 && a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
             else if (a.p_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, true, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);
             else if (a.q_bf16) hipLaunchKernelGGL((wgrad_split_kernel<1, false, true>), dim3((unsigned)blocks), dim3(256), lb, st, a);
             else hipLaunchKernelGGL((wgrad_split_kernel<1, false, false>), dim3((unsigned)blocks), dim3(256), lb, st, a);

@@ -105,6 +105,9 @@ int launch_gemm_gates(const GemmSegs& S, long M, int N, const EpiGates& e, hipSt
 int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st);
 // cell_bwd + dgrad_candidate in one launch (fp32 arithmetic, C % 128 == 0, big-tile regime): see EpiDgrad1's last fields
 bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes);
+int wgrad_tile_option(int value);    // 128 | 256 output rows per tile of the ring kernel (regt_set_option "wgrad_tile")
+bool wgrad_ring_active();             // the ring kernel takes the bf16-stored weight gradients (pairs pay off with it)
+int wgrad_ring_option(int value);    // runtime A/B switch (regt_set_option "wgrad_ring"): ring depth of the bf16 weight gradient
 int dgrad1_gen_option(int value);    // runtime A/B switch (regt_set_option "dgrad1_gen")
 int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hipStream_t st);
 int launch_gemm_dgrad2(const GemmSegs& S, long M, int N, const EpiDgrad2& e, hipStream_t st);
@@ -140,6 +143,7 @@ struct WgradArgs {
     // nin_split).  Two gradients that share P -- dA0 = ds^T x and dA_r = ds^T (L~ x) -- then read P from HBM once.
     const float* Q2 = nullptr; long ldq2 = 0; int nin_split = 0;
     int p_bf16 = 0, q_bf16 = 0;   // P / Q hold bf16 elements (ldp / ldq in elements); vector kernels only
+    int all_csum = 0;             // ring kernel: every column tile forms the column sums (only tile 0 stores them)
 };
 int launch_wgrad(const WgradArgs& a, hipStream_t st);
 long wgrad_slab_stride(const WgradArgs& a);

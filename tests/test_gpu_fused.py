@@ -15,6 +15,7 @@ from oracle import model as M
 from test_gpu_model import _synthetic
 
 pytestmark = pytest.mark.gpu
+DEFAULT_WGRAD_TILE = 256
 
 
 @pytest.fixture()
@@ -22,11 +23,17 @@ def bf16_mode():
     import regtgcn_amd as R
     lib = R.load_library()
     prev = lib.regt_set_gemm_mode(2)
+    # one launch per weight gradient here: the paired launches (default with the ring kernel) only exist on the bf16-row layout and
+    # chunk the rows of dGh / dGzr differently -- the xbf = 0 / 1 comparisons below are about the forward / data-gradient kernels
+    lib.regt_set_option(b"wgrad_pairs", 0)
     yield R
     lib.regt_set_gemm_mode(prev)
     lib.regt_set_option(b"xbf", 1)
     lib.regt_set_option(b"fused_bwd", 1)
     lib.regt_set_option(b"spmm_rows", 0)
+    lib.regt_set_option(b"wgrad_ring", 6)
+    lib.regt_set_option(b"wgrad_tile", DEFAULT_WGRAD_TILE)
+    lib.regt_set_option(b"wgrad_pairs", 2)
 
 
 def test_pack_x_bf16_rounds_to_nearest_even_and_leaves_halo_rows_alone():
@@ -143,6 +150,29 @@ def test_fused_backward_equals_three_launch_backward_bit_for_bit(bf16_mode, n, e
     assert not bad, bad
     a1, a0 = g1["tgnn._attention"], g0["tgnn._attention"]
     assert float((a1 - a0).abs().max()) <= 1e-4 * float(a0.abs().max()) + 1e-7, (a1, a0)
+    assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+# rows per weight-gradient chunk vary with the shape: chunks of fewer half slabs than the ring is deep (600 x 1), chunks that end
+# inside a ring turn, a tail chunk, 20 000 x 12 rows (chunks of hundreds of half slabs)
+@pytest.mark.parametrize("ring,tile,pairs", [(4, 128, 1), (6, 128, 0), (8, 128, 1), (6, 256, 1), (6, 256, 0)])
+@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES[:5] + [(20000, 150000, 8, 64, 12, 1), (37, 200, 2, 64, 3, 1)])
+def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode, ring, tile, pairs, n, e, regions, f, t, o):
+    """wgrad_bf16_ring_kernel<D, MI> (bf16-stored operands requested D half slabs ahead through a register ring; 128- or 256-row
+    output tiles; descriptors that end with the row chunk instead of a row test per step) walks the same half slabs in the same
+    order with the same MFMA as wgrad_split_kernel<1, true, true>: identical slabs, so identical gradients -- with the gradients
+    of a left operand paired in one launch (dhp^T [q | A_hat x], dzr^T [h | A_hat x]) and one launch each."""
+    R = bf16_mode
+    lib = R.load_library()
+    lib.regt_set_option(b"wgrad_pairs", pairs)
+    lib.regt_set_option(b"wgrad_ring", ring)
+    lib.regt_set_option(b"wgrad_tile", tile)
+    p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1)
+    lib.regt_set_option(b"wgrad_ring", 0)
+    p0, h0, g0 = _run(R, n, e, regions, f, t, o, 1)
+    assert torch.equal(p1, p0) and torch.equal(h1, h0) and set(g1) == set(g0)
+    bad = {k: float((g1[k] - g0[k]).abs().max()) for k in g0 if not torch.equal(g1[k], g0[k])}
+    assert not bad, bad
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
 
 
