@@ -328,6 +328,8 @@ def stage_flops(stage, M, C, F):
         "gemm_regional": 2.0 * M * C * 2 * F, "dgrad_candidate": 2.0 * M * C * C, "dgrad_gates": 2.0 * M * C * 2 * C,
         "wgrad_Uh": 2.0 * M * C * C, "wgrad_Uzr": 2.0 * M * 2 * C * C, "wgrad_Gh": 2.0 * M * C * F,
         "wgrad_Gzr": 2.0 * M * 2 * C * F, "wgrad_A0": 2.0 * M * C * F, "wgrad_Ar": 2.0 * M * C * F, "wgrad_A0_Ar": 2.0 * M * C * 2 * F,
+        # paired launches of the bf16-row layout (round 4): dhp^T [q | A_hat x], dzr^T [h | A_hat x]
+        "wgrad_UhGh": 2.0 * M * C * (C + F), "wgrad_UzrGzr": 2.0 * M * 2 * C * (C + F),
     }.get(stage)
 
 
@@ -351,6 +353,7 @@ def stage_bytes(stage, M, C, F, mode=0, xbf=False, gen=False):
         "dgrad_gates": a * (2 * C + C + C) + a * C,                 # read dzp|drp, dh, h; write ds
         "wgrad_Uzr": a * 3 * C, "wgrad_Uh": a * 2 * C, "wgrad_Gzr": a * 2 * C + x * F, "wgrad_Gh": a * C + x * F,
         "wgrad_A0_Ar": a * C + x * 2 * F,
+        "wgrad_UhGh": a * 2 * C + x * F, "wgrad_UzrGzr": a * 3 * C + x * F,      # each operand once: dhp, q, A_hat x / dzr, h, A_hat x
     }.get(stage)
     return None if per_row is None else M * per_row
 
@@ -377,8 +380,8 @@ def stage_kernel(stage, mode):
         return {0: ["gemm_cand_split_kernel<0>", "gemm_cand_flat_kernel<regt::FastCore"],
                 1: ["gemm_cand_split_kernel<3>", "gemm_cand_flat_kernel<regt::SplitCore<false, 3>"],
                 2: ["gemm_cand_split8_kernel", "gemm_cand_flat8_kernel", "gemm_cand_flat_kernel<regt::SplitCore<false, 1>"]}[mode]
-    if stage in ("wgrad_Uzr", "wgrad_Uh"):
-        return ["wgrad_kernel<128"] if mode == 0 else ["wgrad_split_kernel"]
+    if stage in ("wgrad_Uzr", "wgrad_Uh", "wgrad_UhGh", "wgrad_UzrGzr"):
+        return ["wgrad_kernel<128"] if mode == 0 else ["wgrad_bf16_ring_kernel", "wgrad_split_kernel"]
     if stage == "cell_bwd":
         return ["cell_bwd8_kernel", "cell_bwd_kernel"] if mode == 2 else ["cell_bwd_kernel"]
     if stage == "spmm":

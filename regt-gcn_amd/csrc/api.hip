@@ -938,20 +938,22 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     const int pairs_opt = wgrad_pairs_setting();
     const bool pairs = (pairs_opt == 2 ? wgrad_ring_active() : pairs_opt == 1) && ibf && qbf && abf && xbf && !h_ext && !tcol && C % 128 == 0 && F % 8 == 0 && sw == st;
     if (pairs) {
-        WgradArgs a{L.dhp, C, C, L.q, C, C + F, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        int kc = L.kchunk, nc = L.nchunks;
+        wgrad_ring_chunking(C, C + F, M, &kc, &nc);          // one wave of workgroups (ring kernel), else the layout's chunks
+        WgradArgs a{L.dhp, C, C, L.q, C, C + F, 0, M, kc, nullptr, nc, nullptr, 1};
         a.p_bf16 = 1; a.q_bf16 = 1; a.Q2 = L.AX; a.ldq2 = F; a.nin_split = C;
-        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
+        TRY(rq.take((long)nc * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_UhGh", st);
             TRY(launch_wgrad(a, st));
         }
         WgradReduceArgs r{};
-        r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
+        r.slab = a.slab; r.nchunks = nc; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
         r.elem_offset = 0; r.Nout = C; r.Nin = C; r.out = gr.gate_w[2] + C; r.ldo = 2L * C;
         r.colsum_out = L.dch; r.colsum_offset = (long)C * (C + F); r.ncolsum = C;
         TRY(rq.push(r));
         WgradReduceArgs g{};
-        g.slab = a.slab; g.nchunks = L.nchunks; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
+        g.slab = a.slab; g.nchunks = nc; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
         g.elem_offset = C; g.Nout = C; g.Nin = F; g.out = L.dGh; g.ldo = F;
         TRY(rq.push(g));
     } else {
@@ -959,22 +961,24 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
     }
     if (pairs) {
-        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C + F, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        int kc = L.kchunk, nc = L.nchunks;
+        wgrad_ring_chunking(2 * C, C + F, M, &kc, &nc);
+        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C + F, 0, M, kc, nullptr, nc, nullptr, 1};
         a.p_bf16 = 1; a.q_bf16 = 1; a.Q2 = L.AX; a.ldq2 = F; a.nin_split = C;
-        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
+        TRY(rq.take((long)nc * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_UzrGzr", st);
             TRY(launch_wgrad(a, st));
         }
         for (int k = 0; k < 2; ++k) {
             WgradReduceArgs r{};
-            r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
+            r.slab = a.slab; r.nchunks = nc; r.slab_stride = wgrad_slab_stride(a); r.slab_ld = C + F; r.ngroups = 1;
             r.elem_offset = (long)k * C * (C + F); r.Nout = C; r.Nin = C; r.out = gr.gate_w[k] + C; r.ldo = 2L * C;
             r.colsum_out = k == 0 ? L.dczr : nullptr; r.colsum_offset = 2L * C * (C + F); r.ncolsum = 2 * C;
             TRY(rq.push(r));
         }
         WgradReduceArgs g{};
-        g.slab = a.slab; g.nchunks = L.nchunks; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
+        g.slab = a.slab; g.nchunks = nc; g.slab_stride = wgrad_slab_stride(a); g.slab_ld = C + F; g.ngroups = 1;
         g.elem_offset = C; g.Nout = 2 * C; g.Nin = F; g.out = L.dGzr; g.ldo = F;
         TRY(rq.push(g));
     } else if (tcol) {
@@ -1173,6 +1177,7 @@ int32_t regt_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);
     if (!strcmp(name, "wgrad_ring")) return wgrad_ring_option(value);
     if (!strcmp(name, "wgrad_tile")) return wgrad_tile_option(value);
+    if (!strcmp(name, "wgrad_wave")) return wgrad_wave_option(value ? 1 : 0);
     if (!strcmp(name, "wgrad_pairs")) { const int prev = wgrad_pairs_setting(); g_opt_wgrad_pairs = value < 0 || value > 2 ? 2 : value; return prev; }
     if (!strcmp(name, "tgcn_collapse")) { const int prev = tcollapse_wanted() ? 1 : 0; g_opt_tcollapse = value ? 1 : 0; return prev; }
     set_error("regt_set_option: unknown option '%s'", name);

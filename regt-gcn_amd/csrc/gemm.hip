@@ -1155,6 +1155,41 @@ int wgrad_tile_option(int value) {
     return prev;
 }
 bool wgrad_ring_active() { return wgrad_ring_depth() > 0; }
+
+// Row chunking for a ring-kernel launch whose workgroups are ALL resident at once and fill every slot: chunks x tiles = CUs x
+// workgroups per CU.  The tiles of a chunk share their operands through L2 only while they walk the chunk in step; started
+// together they do, started as slots free up (1.5 waves of workgroups at 128 chunks x 6 tiles) they do not, and the half-filled
+// last wave costs as much as a full one.  Fewer, longer chunks also mean fewer slabs to write and reduce.
+// REGT_WGRAD_WAVE=0 / regt_set_option("wgrad_wave", 0): the layout's ~128 chunks.  false: not applicable, keep the caller's chunking.
+static int g_wgrad_wave = -1;
+int wgrad_wave_option(int value) {
+    if (g_wgrad_wave < 0) { const char* e = getenv("REGT_WGRAD_WAVE"); g_wgrad_wave = e ? (atoi(e) ? 1 : 0) : 1; }
+    const int prev = g_wgrad_wave;
+    if (value >= 0) g_wgrad_wave = value ? 1 : 0;
+    return prev;
+}
+bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
+    if (!wgrad_ring_active() || !wgrad_wave_option(-1)) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const bool wide = wgrad_tile_rows() == 256 && Nout % 256 == 0;
+    const int per_cu = wide || wgrad_ring_depth() >= 8 ? 2 : 3;           // register-limited workgroups per CU of the variant launched
+    const long tpc = (long)cdiv(Nout, wide ? 256 : 128) * cdiv(Nin, 128);
+    const long nch = (long)cus * per_cu / tpc;
+    if (nch < 1) return false;
+    long kc = ((M + nch - 1) / nch + 31) / 32 * 32;
+    if (kc < 512) return false;                                            // small problems: many short chunks (latency-bound regime)
+    if (kc > 32768) {                                                      // the kernels' 32-bit row offsets: whole waves of shorter chunks
+        const long waves = (kc + 32767) / 32768;
+        kc = ((M + nch * waves - 1) / (nch * waves) + 31) / 32 * 32;
+    }
+    *kchunk = (int)kc;
+    *nchunks = (int)((M + kc - 1) / kc);
+    return true;
+}
 int wgrad_ring_option(int value) {
     const int prev = wgrad_ring_depth();
     g_wgrad_ring = value < 0 ? 0 : value;

@@ -106,6 +106,8 @@ int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hip
 // cell_bwd + dgrad_candidate in one launch (fp32 arithmetic, C % 128 == 0, big-tile regime): see EpiDgrad1's last fields
 bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes);
 int wgrad_tile_option(int value);    // 128 | 256 output rows per tile of the ring kernel (regt_set_option "wgrad_tile")
+int wgrad_wave_option(int value);    // one-wave row chunking of ring-kernel launches (regt_set_option "wgrad_wave"; -1 = query)
+bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);
 bool wgrad_ring_active();             // the ring kernel takes the bf16-stored weight gradients (pairs pay off with it)
 int wgrad_ring_option(int value);    // runtime A/B switch (regt_set_option "wgrad_ring"): ring depth of the bf16 weight gradient
 int dgrad1_gen_option(int value);    // runtime A/B switch (regt_set_option "dgrad1_gen")

@@ -34,6 +34,7 @@ def bf16_mode():
     lib.regt_set_option(b"wgrad_ring", 6)
     lib.regt_set_option(b"wgrad_tile", DEFAULT_WGRAD_TILE)
     lib.regt_set_option(b"wgrad_pairs", 2)
+    lib.regt_set_option(b"wgrad_wave", 1)
 
 
 def test_pack_x_bf16_rounds_to_nearest_even_and_leaves_halo_rows_alone():
@@ -165,6 +166,7 @@ def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode,
     R = bf16_mode
     lib = R.load_library()
     lib.regt_set_option(b"wgrad_pairs", pairs)
+    lib.regt_set_option(b"wgrad_wave", 0)              # the same row chunks on both sides (the one-wave chunking follows the ring kernel)
     lib.regt_set_option(b"wgrad_ring", ring)
     lib.regt_set_option(b"wgrad_tile", tile)
     p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1)
@@ -174,6 +176,27 @@ def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode,
     bad = {k: float((g1[k] - g0[k]).abs().max()) for k in g0 if not torch.equal(g1[k], g0[k])}
     assert not bad, bad
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+def test_one_wave_row_chunking_of_the_paired_weight_gradients(bf16_mode):
+    """The paired ring-kernel launches cut the rows into as many chunks as fill the GPU once (api.hip / wgrad_ring_chunking) instead
+    of the layout's ~128: the same products summed over other chunk boundaries -- gradients within 2e-5 of their scale, the
+    rest of the step untouched.  40 000 x 12 rows: 170 / 85 chunks of 2 848 / 5 664 rows instead of 128 of 3 776."""
+    R = bf16_mode
+    lib = R.load_library()
+    lib.regt_set_option(b"wgrad_pairs", 1)
+    shape = (40000, 300000, 8, 64, 12, 1)
+    lib.regt_set_option(b"wgrad_wave", 1)
+    p1, h1, g1 = _run(R, *shape, 1)
+    p1b, h1b, g1b = _run(R, *shape, 1)
+    lib.regt_set_option(b"wgrad_wave", 0)
+    p0, h0, g0 = _run(R, *shape, 1)
+    assert torch.equal(p1, p0) and torch.equal(h1, h0) and set(g1) == set(g0)
+    assert all(torch.equal(g1[k], g1b[k]) for k in g1)                       # reproducible
+    changed = [k for k in g0 if not torch.equal(g1[k], g0[k])]
+    assert changed, "the one-wave chunking did not take effect"
+    for k in g0:
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()) + 1e-9, k
 
 
 @pytest.mark.parametrize("n,e,regions,f,t,o", [(300, 2400, 3, 64, 100, 1), (130, 900, 2, 32, 255, 2)])
