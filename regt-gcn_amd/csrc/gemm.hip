@@ -1909,7 +1909,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[mi][j], f.b[ni][j], acc[mi][ni], 0, 0, 0);
     };
     auto colsum = [&](int stage) {
-        if (a.colsum && j0 == 0 && tid < 128) {
+        if (a.colsum && (j0 == 0 || a.all_csum) && tid < 128) {      // (all_csum: same work in every column tile, launch_wgrad)
             const float* lp = lds + stage * (P_TILE + Q_TILE);
 #pragma unroll
             for (int k = 0; k < W_BK; k += 2) {      // two partial sums (even / odd rows): one packed add per two rows
@@ -2035,7 +2035,8 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x2 csum2 = {0.f, 0.f};
-    const bool do_colsum = a.colsum && j0 == 0 && tid < 128;
+    const bool do_colsum = a.colsum && (j0 == 0 || a.all_csum) && tid < 128;      // stored by column tile 0 only
+    const bool store_colsum = a.colsum && j0 == 0 && tid < 128;
 
     // registers of half h of a slab: rp[2 h + s], rq[2 h + s]
     auto load_half = [&](int g, int h, float4 (&rp)[4], float4 (&rq)[4]) {       // g = half-slab index (rows 16 g ..); past the end: zeros
@@ -2151,7 +2152,7 @@ __global__ __launch_bounds__(256, 3) void wgrad3_kernel(WgradArgs a) {
                 }
             }
         }
-    if (do_colsum && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum2[0] + csum2[1];
+    if (store_colsum && i0 + tid < a.Nout) out[(long)a.Nout * a.Nin + i0 + tid] = csum2[0] + csum2[1];
 }
 
 
@@ -2777,7 +2778,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel_generic(WgradArgs a) {
 
 long wgrad_slab_stride(const WgradArgs& a) { return (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0); }
 
+static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st);
+// Every column tile of a row chunk forms the column sums of P although only tile 0 stores them (REGT_WGRAD_SYM=0: tile 0 alone):
+// the tiles of a chunk share P (and Q between row tiles) through their XCD's L2 and only find each other's lines there while they walk
+// the chunk in step -- with less work the other tiles run ahead and every tile reads its operands from HBM (measured on the bf16
+// ring kernel: 0.90 / 0.51 ms against 0.71 / 0.45 ms for the two paired gradients of the cfg-5 shard).
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+    static int sym = -1;
+    if (sym < 0) { const char* e = getenv("REGT_WGRAD_SYM"); sym = e ? atoi(e) : 1; }
+    WgradArgs am = a;
+    am.all_csum = sym && a.colsum && a.p_bf16 && a.q_bf16;     // (fp32 kernels: measured no gain, +0.02 ms on the MFMA-bound wgrad3_kernel)
+    return launch_wgrad_impl(am, st);
+}
+static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
     REGT_CHECK_ARG(a.Nout > 0 && a.Nin > 0 && a.nchunks > 0, "wgrad: empty problem");
     // a two-part right-hand side runs on the skinny fp32 kernel, except under the bf16 arithmetic with Nin <= 128 (one
     // column tile of the bf16-pipe kernel: at F = 64 the fused dA0 / dA_r gradient is fp32-MFMA-bound on the skinny kernel)
@@ -2810,17 +2823,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
             const long ld_max = std::max(a.ldp, std::max(a.ldq, a.Q2 ? a.ldq2 : 0L));
             const long rows_max = a.chunk_tab ? a.M : (long)a.kchunk + 32;
             const bool ring_ok = a.p_bf16 && a.q_bf16 && ring > 0 && (!a.Q2 || a.nin_split % 128 == 0) && 2 * rows_max * ld_max < (1L << 31);
-            // 256-row tiles where the output has them (regt_set_option("wgrad_tile", 128 | 256) / REGT_WGRAD_TILE); ring of 4 there
-            // (6 half slabs of three 16-byte loads spill)
             // experiment: REGT_WGRAD_OCC = 1 | 2 pads the dynamic LDS so that only that many workgroups share a CU
-            // Every column tile forms the column sums of P although only tile 0 stores them (REGT_WGRAD_SYM=0: tile 0 alone): the
-            // tiles of a row chunk share P (and Q between row tiles) through their XCD's L2 and only find each other's lines there
-            // while they walk the chunk in step -- with a third less vector work the other tiles run ahead and every tile reads its
-            // operands from HBM (measured: 0.90 / 0.51 ms against 0.71 / 0.45 ms for the two paired gradients of the cfg-5 shard).
-            static int sym = -1;
-            if (sym < 0) { const char* e = getenv("REGT_WGRAD_SYM"); sym = e ? atoi(e) : 1; }
-            WgradArgs am = a;
-            am.all_csum = sym && a.colsum;
             static int occ = -1;
             if (occ < 0) { const char* e = getenv("REGT_WGRAD_OCC"); occ = e ? atoi(e) : 0; }
             auto padded = [&](size_t need) { return occ > 0 ? std::max(need, (size_t)(160 * 1024 / occ - 1024)) : need; };
@@ -2828,9 +2831,11 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
                 static bool attr_done_r = false;
                 const size_t bytes = padded(need);
                 if (bytes > 48 * 1024) { if (int rc = set_lds_once(kernel, (int)bytes, &attr_done_r)) return rc; }
-                hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(256), bytes, st, am);
+                hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(256), bytes, st, a);
                 return REGT_OK;
             };
+            // 256-row tiles where the output has them (regt_set_option("wgrad_tile", 128 | 256) / REGT_WGRAD_TILE); ring of 4 there
+            // (6 half slabs of three 16-byte loads spill)
             if (ring_ok && wgrad_tile_rows() == 256 && a.Nout % 256 == 0) {
                 const long blocks4 = (long)(a.Nout / 256) * cdiv(a.Nin, 128) * a.nchunks;
                 if (int rc = launch_ring(&wgrad_bf16_ring_kernel<4, 4>, blocks4, 2 * 3 * WS_PLANE_B)) return rc;
