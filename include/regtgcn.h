@@ -319,7 +319,12 @@ int32_t regt_set_gemm_mode(int32_t mode);
  * workgroup's rows held in LDS) instead of the column-panel kernels.  "dgrad1_gen" (default 1): fp32 arithmetic, the candidate data gradient
  * forms its left operand dhp from Z, H~, dOH while staging it and its epilogue writes dzp and the attention dots (no separate
  * cell-backward pass); 0 = the two launches.  "tgcn_collapse" (default 1): regional = 0 (TemporalGCN), fp32 / bf16x3: the gates' linear use of
- * the activation-free hidden input folded into x and L~ x (gate GEMM at K = 3F, no K = 2C gate data gradient); 0 = uncollapsed.  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
+ * the activation-free hidden input folded into x and L~ x (gate GEMM at K = 3F, no K = 2C gate data gradient); 0 = uncollapsed.
+ * Weight gradients of the bf16-row layout (both operands stored as bf16): "wgrad_ring" (default 6): 16-row half slabs requested ahead
+ * through a register ring (4 | 6 | 8); 0 = the one-ahead kernel, same partial sums bit for bit.  "wgrad_tile" (default 256): output
+ * rows per tile (128 | 256).  "wgrad_pairs" (default 2 = on with the ring kernel; 0 | 1): the two gradients of each left operand as
+ * one launch.  "wgrad_wave" (default 1): row chunks of those launches sized so that all their workgroups are resident at once
+ * (another summation order over chunk boundaries than 0, the fixed ~128 chunks).  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
 int32_t regt_set_option(const char* name, int32_t value);
 
 /* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row
