@@ -93,21 +93,21 @@ def test_row_block_kernel_equals_panel_kernel_bit_for_bit(n, e, regions, w):
     assert torch.equal(a1, a0) and torch.equal(l1, l0)
 
 
-def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1):
+def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1, hidden=256):
     lib = R.load_library()
     lib.regt_set_option(b"xbf", xbf)
     lib.regt_set_option(b"fused_bwd", fused_bwd)
     ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n + seed)
     x = bf16_round(x)
     y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
-    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3)
-    mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+    p = M.init_params("RegionalTemporalGCN", f, t, o, num_nodes=n, num_regions=regions, seed=3, hidden=hidden)
+    mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions, hidden_channels=hidden)
     mod.load_state_dict(p, strict=True)
     mod = mod.cuda()
-    pred, hidden = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
-    (torch.mean((pred - y.cuda()) ** 2) + 1e-3 * hidden.sum()).backward()
+    pred, hid = mod(x.cuda(), ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    (torch.mean((pred - y.cuda()) ** 2) + 1e-3 * hid.sum()).backward()
     grads = {k: q.grad.detach().clone() for k, q in mod.named_parameters() if q.grad is not None}
-    return pred.detach(), hidden.detach(), grads
+    return pred.detach(), hid.detach(), grads
 
 
 # (nodes, edges, regions, F, T, O): 64 regions = configs[4]; O = 3; T = 5 and a row count that is no multiple of 64 (tail tile,
@@ -176,6 +176,25 @@ def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode,
     bad = {k: float((g1[k] - g0[k]).abs().max()) for k in g0 if not torch.equal(g1[k], g0[k])}
     assert not bad, bad
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+@pytest.mark.parametrize("hidden", [128, 384, 512])
+def test_ring_weight_gradient_other_hidden_widths(bf16_mode, hidden):
+    """C = 128 (one 128-row tile for dhp, a 256-row tile for dz|dr), 384 (no 256-row tiling of C; 768 = three for 2C), 512: the
+    ring kernel's tile choice follows the output's row count; paired launches need the [C | F] split on a column-tile boundary."""
+    R = bf16_mode
+    lib = R.load_library()
+    shape = (3000, 24000, 4, 64, 12, 1)
+    lib.regt_set_option(b"wgrad_pairs", 1)
+    lib.regt_set_option(b"wgrad_wave", 0)
+    lib.regt_set_option(b"wgrad_ring", 6)
+    p1, h1, g1 = _run(R, *shape, 1, hidden=hidden)
+    lib.regt_set_option(b"wgrad_ring", 0)
+    p0, h0, g0 = _run(R, *shape, 1, hidden=hidden)
+    assert torch.equal(p1, p0) and torch.equal(h1, h0) and set(g1) == set(g0)
+    bad = {k: float((g1[k] - g0[k]).abs().max()) for k in g0 if not torch.equal(g1[k], g0[k])}
+    assert not bad, bad
+    assert float(g1["tgnn._base_tgcn.linear_h.weight"].abs().max()) > 0
 
 
 def test_one_wave_row_chunking_of_the_paired_weight_gradients(bf16_mode):
