@@ -1144,6 +1144,13 @@ static int wgrad_ring_depth() {
     if (g_wgrad_ring < 0) { const char* e = getenv("REGT_WGRAD_RING"); g_wgrad_ring = e ? atoi(e) : 6; }
     return g_wgrad_ring;
 }
+static int g_wgrad_bnw64 = -1;
+int wgrad_bnw64_option(int value) {      // regt_set_option("wgrad_bnw64", 0 | 1); -1 = query
+    if (g_wgrad_bnw64 < 0) { const char* e = getenv("REGT_WGRAD_BNW64"); g_wgrad_bnw64 = e ? (atoi(e) ? 1 : 0) : 1; }
+    const int prev = g_wgrad_bnw64;
+    if (value >= 0) g_wgrad_bnw64 = value ? 1 : 0;
+    return prev;
+}
 static int g_wgrad_tile = -1;
 static int wgrad_tile_rows() {
     if (g_wgrad_tile < 0) { const char* e = getenv("REGT_WGRAD_TILE"); g_wgrad_tile = e && atoi(e) == 128 ? 128 : 256; }
@@ -1760,9 +1767,12 @@ int launch_gemm_candidate(const CandArgs& a, hipStream_t st) {
 constexpr int W_BK = 32;
 constexpr int W_LDP = 128 + 4;
 
+// 64 (round 4): waves 4x1, each 1 x 2 MFMA tiles -- a 64-wide right-hand side ([x | L~ x] at F = 32) as ONE column tile: P crosses
+// HBM / L2 once instead of once per 32 columns and a fragment of P feeds two MFMAs; the two-part right-hand side may split INSIDE it
 template <int BNW, bool PBF = false>   // 128: waves 2x2, each 2x2 MFMA tiles;  32: waves 4x1, each one MFMA tile
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-    constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 128 ? 2 : 1;
+    static_assert(BNW == 128 || BNW == 64 || BNW == 32, "column tile");
+    constexpr int WM = BNW == 128 ? 2 : 1, WN = BNW == 32 ? 1 : 2;
     constexpr int LDQ = BNW + 4;
     constexpr int P_TILE = W_BK * W_LDP, Q_TILE = W_BK * LDQ;
     constexpr int QSLOTS = (W_BK * BNW / 4) / 256;          // float4 slots per thread for Q (4 or 1)
@@ -1810,6 +1820,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     // 8 KB = two 16-byte loads per thread (8 columns each), widened to fp32 on the way into LDS -- this kernel's arithmetic
     // stays the fp32 MFMA
     const bool second = a.Q2 != nullptr && j0 >= a.nin_split;          // this column tile reads the second operand
+    // BNW = 64: the split may run through the tile -- columns past it come from Q2 through a second descriptor (both requested by
+    // every lane with complementary out-of-range offsets, OR-ed: an out-of-range lane returns 0 without touching memory)
+    const bool straddle = BNW == 64 && a.Q2 != nullptr && !second && j0 + BNW > a.nin_split;
     const int ldp = (int)a.ldp, ldq = second ? (int)a.ldq2 : (int)a.ldq;
     // Descriptors based at the chunk's first row with num_records = the chunk's bytes: a row past the chunk's end is out of
     // range (returns 0) without a per-load guard.  Per thread the offsets inside a 32-row slab are constants (a column past
@@ -1820,7 +1833,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     const long pbytes = (long)nrows * ldp * (PBF ? 2 : 4), qbytes = (long)nrows * ldq * 4;
     const __amdgpu_buffer_rsrc_t sp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pbase), 0, (int)(pbytes < 0x7FFFFFF0L ? pbytes : 0x7FFFFFF0L), 0x00020000);
     const __amdgpu_buffer_rsrc_t sq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qbase), 0, (int)(qbytes < 0x7FFFFFF0L ? qbytes : 0x7FFFFFF0L), 0x00020000);
-    int vp[4], vq[QSLOTS];
+    const long q2bytes = straddle ? (long)nrows * a.ldq2 * 4 : 0;
+    const __amdgpu_buffer_rsrc_t sq2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(straddle ? a.Q2 + r0 * a.ldq2 : qbase), 0,
+                                                                         (int)(q2bytes < 0x7FFFFFF0L ? q2bytes : 0x7FFFFFF0L), 0x00020000);
+    int vp[4], vq[QSLOTS], vq2[QSLOTS];
     if (PBF) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -1838,9 +1854,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int s = 0; s < QSLOTS; ++s) {
         const int slot = tid + 256 * s, j = 4 * (slot % (BNW / 4));
-        vq[s] = j0 + j < a.Nin ? 4 * ((slot / (BNW / 4)) * ldq + j) : (int)Core::SRD_OOB;
+        const bool in2 = straddle && j0 + j >= a.nin_split;
+        vq[s] = j0 + j < a.Nin && !in2 ? 4 * ((slot / (BNW / 4)) * ldq + j) : (int)Core::SRD_OOB;
+        vq2[s] = in2 && j0 + j < a.Nin ? 4 * ((slot / (BNW / 4)) * (int)a.ldq2 + (j0 + j - a.nin_split)) : (int)Core::SRD_OOB;
     }
-    const int sp_step = ldp * (PBF ? 2 : 4), sq_step = ldq * 4;      // bytes per row
+    const int sp_step = ldp * (PBF ? 2 : 4), sq_step = ldq * 4, sq2_step = (int)a.ldq2 * 4;      // bytes per row
 
     auto load = [&](int k0, float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
         const int sop = k0 * sp_step, soq = k0 * sq_step;
@@ -1857,6 +1875,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
 #pragma unroll
         for (int s = 0; s < QSLOTS; ++s) rq[s] = buf_ld4(sq, vq[s], soq);
+        if (BNW == 64) {        // unconditional (a tile that does not straddle the split has out-of-range offsets here): no branch around loads
+#pragma unroll
+            for (int s = 0; s < QSLOTS; ++s) {
+                const float4 v = buf_ld4(sq2, vq2[s], k0 * sq2_step);
+                rq[s].x = __uint_as_float(__float_as_uint(rq[s].x) | __float_as_uint(v.x));
+                rq[s].y = __uint_as_float(__float_as_uint(rq[s].y) | __float_as_uint(v.y));
+                rq[s].z = __uint_as_float(__float_as_uint(rq[s].z) | __float_as_uint(v.z));
+                rq[s].w = __uint_as_float(__float_as_uint(rq[s].w) | __float_as_uint(v.w));
+            }
+        }
     };
     auto store = [&](int stage, const float4 (&rp)[4], float4 (&rq)[QSLOTS]) {
         float* lp = lds + stage * (P_TILE + Q_TILE);
@@ -2800,13 +2828,16 @@ static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
     // (a bf16-stored right-hand side of width <= 32 -- A_hat x rows at F = 32 -- also takes the bf16-pipe kernel: the skinny one
     // stages fp32 rows only; the stage is HBM-bound on its left operand either way)
     const bool wide = (a.Nin > 32 || (a.q_bf16 && gemm_mode() == 2 && !a.Q2)) && (!a.Q2 || q2_split);
-    const int bnw = wide ? 128 : 32;
-    long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
-    REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
-    size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
     const bool fast = a.ldp % 4 == 0 && a.ldq % 4 == 0 && a.Nout % 4 == 0 && a.Nin % 4 == 0 && a16(a.P) && a16(a.Q) &&
                       a.ldp < (1L << 20) && a.ldq < (1L << 20) && (a.chunk_tab || a.kchunk <= 65536) &&
                       (!a.Q2 || (a.ldq2 % 4 == 0 && a.ldq2 < (1L << 20) && a16(a.Q2) && a.nin_split % 32 == 0));
+    // (fp32 rows, 32 < Nin <= 64 -- the fused [x | L~ x] right-hand side at F = 32: one 64-column tile; REGT_WGRAD_BNW64=0: two of 32)
+    const int bnw64 = wgrad_bnw64_option(-1);
+    const bool mid = !wide && fast && bnw64 && !a.p_bf16 && !a.q_bf16 && a.Nin > 32 && a.Nin <= 64 && (!a.Q2 || a.nin_split < 64);
+    const int bnw = wide ? 128 : (mid ? 64 : 32);
+    long blocks = (long)cdiv(a.Nout, 128) * cdiv(a.Nin, bnw) * a.nchunks;
+    REGT_CHECK_ARG(blocks < (1L << 31), "wgrad: too many blocks");
+    size_t lds = 2 * (size_t)(W_BK * W_LDP + W_BK * (bnw + 4)) * 4;
     REGT_CHECK_ARG(!a.Q2 || fast, "wgrad: a second right-hand operand needs 16-byte tileable operands and nin_split %% 32 == 0");
     REGT_CHECK_ARG(!(a.p_bf16 || a.q_bf16) || fast, "wgrad: bf16 operands need the vector kernels");
     if (wide) {
@@ -2861,6 +2892,11 @@ static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
     } else if (fast) {
         REGT_CHECK_ARG(!a.q_bf16 && (!a.p_bf16 || (a.Nout % 8 == 0 && a.ldp % 8 == 0)), "wgrad: skinny kernel takes a bf16-stored P only");
         if (a.p_bf16) hipLaunchKernelGGL((wgrad_kernel<32, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+        else if (mid) {
+            static bool attr_done_m = false;
+            if (int rc = set_lds_once(&wgrad_kernel<64>, (int)lds, &attr_done_m)) return rc;      // 51 200 B of dynamic LDS
+            hipLaunchKernelGGL(wgrad_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, st, a);
+        }
         else hipLaunchKernelGGL(wgrad_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);
     } else {
         hipLaunchKernelGGL(wgrad_kernel_generic<32>, dim3((unsigned)blocks), dim3(256), lds, st, a);

@@ -289,6 +289,45 @@ def test_generated_candidate_dgrad_equals_the_two_launch_path(n, e, regions, f, 
             assert torch.equal(res[0][k], res[1][k]), k
 
 
+@pytest.mark.parametrize("n,e,regions,f,t,model", [(3000, 24000, 8, 32, 12, "regt"), (1409, 9000, 3, 32, 5, "regt"), (2500, 20000, 1, 32, 6, "tgcn"),
+                                                    (900, 6000, 2, 24, 12, "regt")])
+def test_sixty_four_wide_weight_gradient_tile_equals_two_of_thirty_two(n, e, regions, f, t, model):
+    """fp32: the fused dA0 | dA_r gradient ds^T [x | L~ x] (and TemporalGCN's dzr^T [x | L~ x]) at F = 32 is 64 columns wide: one
+    64-column tile whose two-part right-hand side splits INSIDE the tile (wgrad_kernel<64>) instead of two 32-column tiles that
+    each read ds.  Same products, same k order per output element: every gradient bit-identical.  F = 24: not a case of it."""
+    import regtgcn_amd as R
+    from oracle import model as M
+    from test_gpu_model import _synthetic
+    lib = R.load_library()
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n)
+    y = torch.rand(n, 1, generator=torch.Generator().manual_seed(1)).cuda()
+    if model == "regt":
+        p = M.init_params("RegionalTemporalGCN", f, t, 1, num_nodes=n, num_regions=regions, seed=3)
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=1, num_regions=regions)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        graph = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+    else:
+        p = M.init_params("TemporalGCN", f, t, 1, seed=3)
+        mod = R.TemporalGCN(node_features=f, periods=t, output_dim=1)
+        mod.load_state_dict(p, strict=True)
+        mod = mod.cuda()
+        graph = mod.prepare_graph(ei.cuda(), None, n)
+    res = {}
+    for on in (1, 0):
+        prev = lib.regt_set_option(b"wgrad_bnw64", on)
+        try:
+            mod.zero_grad(set_to_none=True)
+            pred, hidden = mod.forward_prepared(x.cuda(), graph)
+            (R.functional.mse_loss(pred, y) + (hidden ** 2).mean()).backward()
+            res[on] = {k: q.grad.clone() for k, q in mod.named_parameters() if q.grad is not None}
+        finally:
+            lib.regt_set_option(b"wgrad_bnw64", prev)
+    assert set(res[0]) == set(res[1])
+    bad = {k: float((res[0][k] - res[1][k]).abs().max()) for k in res[0] if not torch.equal(res[0][k], res[1][k])}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("n,e,f,t,o", [(3000, 24000, 32, 12, 1), (1409, 9000, 8, 6, 2), (104, 400, 8, 12, 1)])
 def test_temporal_gcn_collapsed_gates_equal_the_uncollapsed_form(n, e, f, t, o):
     """TemporalGCN's hidden input has no activation (models/TemporalGCN.py:88), so the gates' use of it folds into x and L~ x
