@@ -1177,6 +1177,7 @@ int32_t regt_set_option(const char* name, int32_t value) {
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);
     if (!strcmp(name, "wgrad_ring")) return wgrad_ring_option(value);
     if (!strcmp(name, "wgrad_tile")) return wgrad_tile_option(value);
+    if (!strcmp(name, "wgrad_ring256")) return wgrad_ring256_option(value == 4 ? 4 : 2);
     if (!strcmp(name, "wgrad_bnw64")) return wgrad_bnw64_option(value ? 1 : 0);
     if (!strcmp(name, "wgrad_wave")) return wgrad_wave_option(value ? 1 : 0);
     if (!strcmp(name, "wgrad_pairs")) { const int prev = wgrad_pairs_setting(); g_opt_wgrad_pairs = value < 0 || value > 2 ? 2 : value; return prev; }

@@ -1144,6 +1144,13 @@ static int wgrad_ring_depth() {
     if (g_wgrad_ring < 0) { const char* e = getenv("REGT_WGRAD_RING"); g_wgrad_ring = e ? atoi(e) : 6; }
     return g_wgrad_ring;
 }
+static int g_wgrad_ring256 = -1;
+int wgrad_ring256_option(int value) {      // ring depth of the 256-row tile variant: 2 (default) | 4; -1 = query
+    if (g_wgrad_ring256 < 0) { const char* e = getenv("REGT_WGRAD_RING256"); g_wgrad_ring256 = e && atoi(e) == 4 ? 4 : 2; }
+    const int prev = g_wgrad_ring256;
+    if (value >= 0) g_wgrad_ring256 = value == 4 ? 4 : 2;
+    return prev;
+}
 static int g_wgrad_bnw64 = -1;
 int wgrad_bnw64_option(int value) {      // regt_set_option("wgrad_bnw64", 0 | 1); -1 = query
     if (g_wgrad_bnw64 < 0) { const char* e = getenv("REGT_WGRAD_BNW64"); g_wgrad_bnw64 = e ? (atoi(e) ? 1 : 0) : 1; }
@@ -2865,11 +2872,14 @@ static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
                 hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(256), bytes, st, a);
                 return REGT_OK;
             };
-            // 256-row tiles where the output has them (regt_set_option("wgrad_tile", 128 | 256) / REGT_WGRAD_TILE); ring of 4 there
-            // (6 half slabs of three 16-byte loads spill)
+            // 256-row tiles where the output has them (regt_set_option("wgrad_tile", 128 | 256) / REGT_WGRAD_TILE); ring of 2 there
+            // (REGT_WGRAD_RING256 / "wgrad_ring256" = 2 | 4; 6 half slabs of three 16-byte loads spill).  Two beats four, 0.585 + 0.350
+            // against 0.63 + 0.383 ms at the cfg-5 shard: what is in flight (workgroups x slots x 12 KB per XCD) competes with the lines
+            // the chunk's other tiles are about to ask for in the 4 MiB L2, and the tile that comes second finds its rows there anyway
             if (ring_ok && wgrad_tile_rows() == 256 && a.Nout % 256 == 0) {
                 const long blocks4 = (long)(a.Nout / 256) * cdiv(a.Nin, 128) * a.nchunks;
-                if (int rc = launch_ring(&wgrad_bf16_ring_kernel<4, 4>, blocks4, 2 * 3 * WS_PLANE_B)) return rc;
+                if (wgrad_ring256_option(-1) == 2) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<2, 4>, blocks4, 2 * 3 * WS_PLANE_B)) return rc; }
+                else if (int rc = launch_ring(&wgrad_bf16_ring_kernel<4, 4>, blocks4, 2 * 3 * WS_PLANE_B)) return rc;
             }
             else if (ring_ok && ring >= 8) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<8, 2>, blocks, lb)) return rc; }
             else if (ring_ok && ring >= 6) { if (int rc = launch_ring(&wgrad_bf16_ring_kernel<6, 2>, blocks, lb)) return rc; }

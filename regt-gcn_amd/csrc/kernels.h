@@ -106,6 +106,7 @@ int launch_gemm_dgrad1(const GemmSegs& S, long M, int N, const EpiDgrad1& e, hip
 // cell_bwd + dgrad_candidate in one launch (fp32 arithmetic, C % 128 == 0, big-tile regime): see EpiDgrad1's last fields
 bool gemm_dgrad1_gen_ok(long M, int C, int num_nodes);
 int wgrad_bnw64_option(int value);   // fp32 rows: one 64-column tile for a 33..64-wide right-hand side (regt_set_option "wgrad_bnw64")
+int wgrad_ring256_option(int value);  // ring depth of the 256-row tile (2 | 4)
 int wgrad_tile_option(int value);    // 128 | 256 output rows per tile of the ring kernel (regt_set_option "wgrad_tile")
 int wgrad_wave_option(int value);    // one-wave row chunking of ring-kernel launches (regt_set_option "wgrad_wave"; -1 = query)
 bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);

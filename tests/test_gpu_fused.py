@@ -35,6 +35,7 @@ def bf16_mode():
     lib.regt_set_option(b"wgrad_tile", DEFAULT_WGRAD_TILE)
     lib.regt_set_option(b"wgrad_pairs", 2)
     lib.regt_set_option(b"wgrad_wave", 1)
+    lib.regt_set_option(b"wgrad_ring256", 2)
 
 
 def test_pack_x_bf16_rounds_to_nearest_even_and_leaves_halo_rows_alone():
@@ -156,7 +157,7 @@ def test_fused_backward_equals_three_launch_backward_bit_for_bit(bf16_mode, n, e
 
 # rows per weight-gradient chunk vary with the shape: chunks of fewer half slabs than the ring is deep (600 x 1), chunks that end
 # inside a ring turn, a tail chunk, 20 000 x 12 rows (chunks of hundreds of half slabs)
-@pytest.mark.parametrize("ring,tile,pairs", [(4, 128, 1), (6, 128, 0), (8, 128, 1), (6, 256, 1), (6, 256, 0)])
+@pytest.mark.parametrize("ring,tile,pairs", [(4, 128, 1), (6, 128, 0), (8, 128, 1), (6, 256, 1), (6, 256, 0), (6, 1024 + 256, 1)])
 @pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES[:5] + [(20000, 150000, 8, 64, 12, 1), (37, 200, 2, 64, 3, 1)])
 def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode, ring, tile, pairs, n, e, regions, f, t, o):
     """wgrad_bf16_ring_kernel<D, MI> (bf16-stored operands requested D half slabs ahead through a register ring; 128- or 256-row
@@ -168,7 +169,8 @@ def test_ring_weight_gradient_equals_the_one_ahead_kernel_bit_for_bit(bf16_mode,
     lib.regt_set_option(b"wgrad_pairs", pairs)
     lib.regt_set_option(b"wgrad_wave", 0)              # the same row chunks on both sides (the one-wave chunking follows the ring kernel)
     lib.regt_set_option(b"wgrad_ring", ring)
-    lib.regt_set_option(b"wgrad_tile", tile)
+    lib.regt_set_option(b"wgrad_tile", tile & 1023)
+    lib.regt_set_option(b"wgrad_ring256", 4 if tile > 1024 else 2)         # (1024 + 256: the 256-row tile with a ring of 4)
     p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1)
     lib.regt_set_option(b"wgrad_ring", 0)
     p0, h0, g0 = _run(R, n, e, regions, f, t, o, 1)
