@@ -957,7 +957,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         g.elem_offset = C; g.Nout = C; g.Nin = F; g.out = L.dGh; g.ldo = F;
         TRY(rq.push(g));
     } else {
-    TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, L.kchunk, L.nchunks, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
+    {
+        int kc = L.kchunk, nc = L.nchunks;
+        if (!ibf && !qbf) wgrad_wide_chunking(C, C, M, &kc, &nc);
+        TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, kc, nc, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
+    }
     TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
     }
     if (pairs) {
@@ -1002,16 +1006,18 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             TRY(rq.push(r));
         }
     } else {   // [dUz2; dUr2] = dzr^T h, column sums -> [dcz; dcr]
-        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, L.kchunk, nullptr, L.nchunks, nullptr, 1};
+        int kc = L.kchunk, nc = L.nchunks;
+        if (!ibf && !abf) wgrad_wide_chunking(2 * C, C, M, &kc, &nc);
+        WgradArgs a{L.dzr, 2L * C, 2 * C, H, C, C, 0, M, kc, nullptr, nc, nullptr, 1};
         a.p_bf16 = ibf; a.q_bf16 = abf;
-        TRY(rq.take((long)L.nchunks * wgrad_slab_stride(a), &a.slab));
+        TRY(rq.take((long)nc * wgrad_slab_stride(a), &a.slab));
         {
             PROF("wgrad_Uzr", st);
             TRY(launch_wgrad(a, st));
         }
         for (int k = 0; k < 2; ++k) {
             WgradReduceArgs r{};
-            r.slab = a.slab; r.nchunks = L.nchunks; r.slab_stride = wgrad_slab_stride(a);
+            r.slab = a.slab; r.nchunks = nc; r.slab_stride = wgrad_slab_stride(a);
             r.elem_offset = (long)k * C * C; r.Nout = C; r.Nin = C; r.ngroups = 1;
             r.out = gr.gate_w[k] + C; r.ldo = 2L * C;
             r.colsum_out = k == 0 ? L.dczr : nullptr; r.colsum_offset = 2L * C * C; r.ncolsum = 2 * C;

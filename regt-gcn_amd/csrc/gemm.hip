@@ -1182,6 +1182,33 @@ int wgrad_wave_option(int value) {
     if (value >= 0) g_wgrad_wave = value ? 1 : 0;
     return prev;
 }
+// The same for the wide fp32 / bf16x3 kernels (wgrad3_kernel: three workgroups per CU; wgrad_split_kernel<3>: two): chunks x
+// (128 x 128 tiles) = one full wave of workgroups instead of ~128 chunks (768 instead of 1024 / 512 workgroups for dUzr / dUh at
+// C = 256).  These kernels are MFMA-bound, so it buys little: -0.05 ms of 4.0 at cfg-3, -0.01 ms at the W = 8 shard shape
+// (profiles/r04_wgrad_wave32_ab.txt).  REGT_WGRAD_WAVE32=0: the layout's chunks; =2: two waves (more slabs to reduce: slower).
+static int g_wgrad_wave32 = -1;
+bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
+    if (g_wgrad_wave32 < 0) { const char* e = getenv("REGT_WGRAD_WAVE32"); g_wgrad_wave32 = e ? atoi(e) : 1; }
+    if (!g_wgrad_wave32 || gemm_mode() == 2 || fp32_core_wide() || Nin <= 32) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const int per_cu = gemm_mode() == 1 ? 2 : 3;
+    const long tpc = (long)cdiv(Nout, 128) * cdiv(Nin, 128);
+    long nch = (long)cus * per_cu * g_wgrad_wave32 / tpc;       // g_wgrad_wave32 waves of workgroups
+    if (nch < 1) return false;
+    long kc = ((M + nch - 1) / nch + 31) / 32 * 32;
+    if (kc < 512) return false;
+    if (kc > 32768) {
+        const long waves = (kc + 32767) / 32768;
+        kc = ((M + nch * waves - 1) / (nch * waves) + 31) / 32 * 32;
+    }
+    *kchunk = (int)kc;
+    *nchunks = (int)((M + kc - 1) / kc);
+    return true;
+}
 bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
     if (!wgrad_ring_active() || !wgrad_wave_option(-1)) return false;
     static int cus = 0;
