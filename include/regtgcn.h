@@ -322,9 +322,10 @@ int32_t regt_set_gemm_mode(int32_t mode);
  * the activation-free hidden input folded into x and L~ x (gate GEMM at K = 3F, no K = 2C gate data gradient); 0 = uncollapsed.
  * Weight gradients of the bf16-row layout (both operands stored as bf16): "wgrad_ring" (default 6): 16-row half slabs requested ahead
  * through a register ring (4 | 6 | 8); 0 = the one-ahead kernel, same partial sums bit for bit.  "wgrad_tile" (default 256): output
- * rows per tile (128 | 256).  "wgrad_pairs" (default 2 = on with the ring kernel; 0 | 1): the two gradients of each left operand as
+ * rows per tile (128 | 256); "wgrad_ring256" (default 2): ring depth of the 256-row tile (2 | 4).  "wgrad_pairs" (default 2 = on with the ring kernel; 0 | 1): the two gradients of each left operand as
  * one launch.  "wgrad_wave" (default 1): row chunks of those launches sized so that all their workgroups are resident at once
- * (another summation order over chunk boundaries than 0, the fixed ~128 chunks).  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
+ * (another summation order over chunk boundaries than 0, the fixed ~128 chunks).  "wgrad_bnw64" (default 1): fp32 rows, a 33..64-wide
+ * right-hand side ([x | L~ x] at F = 32) as one 64-column tile instead of two of 32 (bit-identical).  "xbf" / "fused_bwd" also exist per call: regt_dims.flags. */
 int32_t regt_set_option(const char* name, int32_t value);
 
 /* Developer hook (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of the last fused forward launch, 8 per 64-row
