@@ -318,6 +318,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.kchunk = (int)kc;
     L.nchunks = (int)((M + kc - 1) / kc);
     long ks = ((M + 511) / 512 + 31) / 32 * 32;     // skinny (C x F) gradients: memory-bound, want >= 1024 small workgroups
+                                                    // (dGh / dGzr on fp32 rows pick their own count per launch: wgrad_skinny_chunking)
     if (ks < 128) ks = 128;
     L.kchunk_s = (int)ks;
     L.nchunks_s = (int)((M + ks - 1) / ks);
@@ -962,7 +963,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         if (!ibf && !qbf) wgrad_wide_chunking(C, C, M, &kc, &nc);
         TRY(wgrad_full(rq, "wgrad_Uh", L.dhp, C, C, L.q, C, C, 0, M, kc, nc, gr.gate_w[2] + C, 2L * C, L.dch, st, ibf, qbf));
     }
-    TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGh, F, nullptr, sw, ibf, xbf));
+    {
+        int kc = L.kchunk_s, nc = L.nchunks_s;
+        if (!ibf && !xbf && F <= 32) wgrad_skinny_chunking(C, M, &kc, &nc);
+        TRY(wgrad_full(rq, "wgrad_Gh", L.dhp, C, C, L.AX, F, F, 0, M, kc, nc, L.dGh, F, nullptr, sw, ibf, xbf));
+    }
     }
     if (pairs) {
         int kc = L.kchunk, nc = L.nchunks;
@@ -1027,7 +1032,11 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // (One launch per pair with a two-part right-hand side [q | A_hat x] / [h | A_hat x] -- so that dhp and dzp|drp are read
     // once -- was measured and is slower: 1.86 vs 1.44 ms for the four at the cfg-5 shard; the third, half-empty column tile and
     // the doubled load instructions of the two-descriptor staging cost more than the second pass over the left operand.)
-    if (!pairs) TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, L.kchunk_s, L.nchunks_s, L.dGzr, F, nullptr, sw, ibf, xbf));
+    if (!pairs) {
+        int kc = L.kchunk_s, nc = L.nchunks_s;
+        if (!ibf && !xbf && F <= 32) wgrad_skinny_chunking(2 * C, M, &kc, &nc);
+        TRY(wgrad_full(rq, "wgrad_Gzr", L.dzr, 2L * C, 2 * C, L.AX, F, F, 0, M, kc, nc, L.dGzr, F, nullptr, sw, ibf, xbf));
+    }
     float* dA0 = d.regional ? L.dA0 : gr.cheb_w0;
     float* dAall = d.regional ? L.dAall : gr.cheb_w1;
     float* dbpr = d.regional ? L.dbprime : gr.cheb_bias;

@@ -1209,6 +1209,29 @@ bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
     *nchunks = (int)((M + kc - 1) / kc);
     return true;
 }
+// Skinny gradients (Nin <= 32: wgrad_kernel<32>, HBM-bound on their left operand): chunks x row tiles = REGT_WGRAD_SKINNY (default 2)
+// workgroups per CU, all resident at once -- at cfg-3 the layout's 507 chunks are 1.3 (dGh) / 2.6 (dGzr) waves of workgroups.
+bool wgrad_skinny_chunking(int Nout, long M, int* kchunk, int* nchunks) {
+    static int per_cu = -1;
+    if (per_cu < 0) { const char* e = getenv("REGT_WGRAD_SKINNY"); per_cu = e ? atoi(e) : 2; }
+    if (per_cu <= 0) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    const long nch = (long)cus * per_cu / cdiv(Nout, 128);
+    if (nch < 1) return false;
+    long kc = ((M + nch - 1) / nch + 31) / 32 * 32;
+    if (kc < 512) return false;
+    if (kc > 32768) {
+        const long waves = (kc + 32767) / 32768;
+        kc = ((M + nch * waves - 1) / (nch * waves) + 31) / 32 * 32;
+    }
+    *kchunk = (int)kc;
+    *nchunks = (int)((M + kc - 1) / kc);
+    return true;
+}
 bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
     if (!wgrad_ring_active() || !wgrad_wave_option(-1)) return false;
     static int cus = 0;

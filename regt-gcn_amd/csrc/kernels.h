@@ -110,6 +110,7 @@ int wgrad_ring256_option(int value);  // ring depth of the 256-row tile (2 | 4)
 int wgrad_tile_option(int value);    // 128 | 256 output rows per tile of the ring kernel (regt_set_option "wgrad_tile")
 int wgrad_wave_option(int value);    // one-wave row chunking of ring-kernel launches (regt_set_option "wgrad_wave"; -1 = query)
 bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);
+bool wgrad_skinny_chunking(int Nout, long M, int* kchunk, int* nchunks);            // skinny (Nin <= 32) fp32-MFMA kernel
 bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);   // wide fp32 / bf16x3 kernels (experiment)
 bool wgrad_ring_active();             // the ring kernel takes the bf16-stored weight gradients (pairs pay off with it)
 int wgrad_ring_option(int value);    // runtime A/B switch (regt_set_option "wgrad_ring"): ring depth of the bf16 weight gradient
