@@ -996,15 +996,17 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         // the 32-column tile, else one launch per part.
         const bool two = F % 32 == 0;
         for (int part = 0; part < (two ? 1 : 2); ++part) {
-            WgradArgs a{L.dzr, 2L * C, 2 * C, part ? L.LX : Xp, F, two ? 2 * F : F, 0, M, L.kchunk_s, nullptr, L.nchunks_s, nullptr, part == 0 ? 1 : 0};
+            int kcs = L.kchunk_s, ncs = L.nchunks_s;
+            if (!ibf && !xbf && (two ? 2 * F : F) <= 64) wgrad_skinny_chunking(2 * C, M, &kcs, &ncs);      // one wave of workgroups
+            WgradArgs a{L.dzr, 2L * C, 2 * C, part ? L.LX : Xp, F, two ? 2 * F : F, 0, M, kcs, nullptr, ncs, nullptr, part == 0 ? 1 : 0};
             if (two) { a.Q2 = L.LX; a.ldq2 = F; a.nin_split = F; }
-            TRY(rq.take((long)L.nchunks_s * wgrad_slab_stride(a), &a.slab));
+            TRY(rq.take((long)ncs * wgrad_slab_stride(a), &a.slab));
             {
                 PROF("wgrad_P01", st);
                 TRY(launch_wgrad(a, st));
             }
             WgradReduceArgs r{};
-            r.slab = a.slab; r.nchunks = L.nchunks_s; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
+            r.slab = a.slab; r.nchunks = ncs; r.slab_stride = wgrad_slab_stride(a); r.elem_offset = 0;
             r.Nout = 2 * C; r.Nin = two ? 2 * F : F; r.ngroups = 1;
             r.out = L.dP01 + (two ? 0 : part * F); r.ldo = 2L * F;
             r.colsum_out = part == 0 ? L.dczr : nullptr; r.colsum_offset = (long)2 * C * (two ? 2 * F : F); r.ncolsum = 2 * C;
