@@ -44,6 +44,23 @@ def test_host_side_validation_without_gpu():
     assert lib.regt_wgrad_slab_floats(1000, 256, 256, 1) >= 256 * 256 + 256
 
 
+def test_developer_options_are_host_state_and_every_documented_name_is_known():
+    """regt_set_option touches no GPU: every option name the header documents is accepted, returns the previous value and can be
+    restored; an unknown name is refused with -1 and a message."""
+    lib = R.load_library()
+    src = open(os.path.join(ROOT, "include", "regtgcn.h")).read()
+    doc = src[src.index("Developer switches"):src.index("int32_t regt_set_option")]
+    names = sorted(set(re.findall(r'"([a-z_0-9]+)"', doc)))
+    assert {"xbf", "fused_bwd", "spmm_rows", "dgrad1_gen", "tgcn_collapse", "wgrad_ring", "wgrad_tile", "wgrad_ring256", "wgrad_pairs",
+            "wgrad_wave", "wgrad_bnw64"} <= set(names), names
+    for n in names:
+        prev = lib.regt_set_option(n.encode(), 1)
+        assert prev >= 0, (n, lib.regt_last_error())
+        assert lib.regt_set_option(n.encode(), prev) >= 0          # restored (the value just set is returned)
+        assert lib.regt_set_option(n.encode(), prev) == prev
+    assert lib.regt_set_option(b"no_such_option", 1) == -1 and b"unknown option" in lib.regt_last_error()
+
+
 def test_modules_refuse_cpu_tensors_and_keep_reference_layout():
     m = R.RegionalTemporalGCN(node_features=8, num_nodes=104, periods=6, output_dim=1)
     sd = torch.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_in6_out1_epoch50.pt"), map_location="cpu", weights_only=True)
