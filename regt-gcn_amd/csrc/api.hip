@@ -382,17 +382,22 @@ SmallGemm sg(const float* A, long sai, long sak, long sab, const float* B, long 
     return SmallGemm{A, sai, sak, sab, B, sbk, sbj, sbb, C, sci, scj, scb, m, n, k, batch, sum_batch, accumulate};
 }
 
+inline bool fits32(long v) { return v >= INT_MIN && v <= INT_MAX; }
 SgTerm term(const float* A, long sai, long sak, long sab, const float* B, long sbk, long sbj, long sbb, int k, int batch = 1,
             int sum_batch = 0) {
-    return SgTerm{A, sai, sak, sab, B, sbk, sbj, sbb, k, batch, sum_batch};
+    const bool ok = fits32(sai) && fits32(sak) && fits32(sab) && fits32(sbk) && fits32(sbj) && fits32(sbb) && batch <= SHRT_MAX && k >= 0;
+    return SgTerm{A, B, (int)sai, (int)sak, (int)sab, (int)sbk, (int)sbj, (int)sbb, ok ? k : -1, (short)batch, (short)sum_batch};
 }
 void add_task(SgBatch& b, float* C, long sci, long scj, long scb, int m, int n, int nbatch, const float* init, long init_si,
               std::initializer_list<SgTerm> terms, long init_sj = 0) {
-    if (b.ntask >= SG_MAX_TASKS) { b.overflow = 1; return; }
+    bool ok = b.ntask < SG_MAX_TASKS && fits32(sci) && fits32(scj) && fits32(scb) && fits32(init_si) && fits32(init_sj) && nbatch <= SHRT_MAX &&
+              terms.size() <= 3;
+    for (const SgTerm& q : terms) ok = ok && q.k >= 0;
+    if (!ok) { b.overflow = 1; return; }
     SgTask& t = b.task[b.ntask++];
     t = SgTask{};
-    t.C = C; t.sci = sci; t.scj = scj; t.scb = scb; t.m = m; t.n = n; t.nbatch = nbatch; t.init = init; t.init_si = init_si;
-    t.init_sj = init_sj;
+    t.C = C; t.sci = (int)sci; t.scj = (int)scj; t.scb = (int)scb; t.m = m; t.n = n; t.nbatch = (short)nbatch; t.init = init;
+    t.init_si = (int)init_si; t.init_sj = (int)init_sj;
     for (const SgTerm& q : terms) t.term[t.nterm++] = q;
 }
 
@@ -1094,7 +1099,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         TRY(wgrad_full(rq, "wgrad_Ar", L.dh, C, C, L.LX, F, F, 0, M, L.kchunk_s, L.nchunks_s, dAall, F, nullptr, st, abf, 0));
     }
     TRY(rq.flush());      // every slab reduction of this backward pass, one launch
-    // ---- back through the weight compositions (tiny; two launches) ---------------------------------------
+    // ---- back through the weight compositions (tiny; one launch) ------------------------------------------
     PROF("compose_bwd", st);
     {
         SgBatch b{};
@@ -1110,13 +1115,8 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             add_task(b, gr.conv_lin_w[k], 1, F, 0, F, C, 1, nullptr, 0, {term(dG, 1, F, 0, p.gate_w[k], 2L * C, 1, 0, C)});
             add_task(b, gr.conv_bias[k], 1, 0, 0, C, 1, 1, nullptr, 0, {term(p.gate_w[k], 1, 2L * C, 0, dc, 1, 0, 0, C)});
         }
-        if (d.regional)      // G0 = dA0 W0^T + db' b_c^T: what EVERY block of d tgnn.linear.weight receives (A0 and b' sum over all regions)
-            add_task(b, L.G0, C, 1, 0, C, C, 1, nullptr, 0,
-                     {term(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, F), term(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, 1)});
-        TRY(launch_small_gemm_multi(b, st));
-    }
-    {
-        SgBatch b{};
+        // (one launch since round 4: nothing below reads what the tasks above write -- G0 = dA0 W0^T + db' b_c^T, what EVERY
+        // block of d tgnn.linear.weight receives, is summed inside each block's task instead of through a buffer)
         for (int k = 0; k < 3; ++k)      // du_k = dc_k
             add_task(b, gr.gate_b[k], 1, 0, 0, C, 1, 1, k < 2 ? L.dczr + (long)k * C : L.dch, 1, {});
         if (tcol) {
@@ -1142,11 +1142,13 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
             const long RC = (long)R * C;
             int lo, hi;
             region_range(d, g, &lo, &hi);
-            // dWl_r = G0 + dA_r W1^T for the owned regions, G0 alone for the others (their rows live on other GPUs)
-            add_task(b, gr.region_w + (long)lo * C, RC, 1, C, C, C, hi - lo, L.G0, C,
-                     {term(L.dAall + (long)lo * C * F, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, F)}, 1);
-            if (lo > 0) add_task(b, gr.region_w, RC, 1, C, C, C, lo, L.G0, C, {}, 1);
-            if (hi < R) add_task(b, gr.region_w + (long)hi * C, RC, 1, C, C, C, R - hi, L.G0, C, {}, 1);
+            // dWl_r = G0 + dA_r W1^T for the owned regions, G0 alone for the others (their rows live on other GPUs);
+            // G0 = dA0 W0^T + db' b_c^T (A0 and b' sum over all regions)
+            const SgTerm g0a = term(L.dA0, F, 1, 0, p.cheb_w0, 1, F, 0, F), g0b = term(L.dbprime, 1, 0, 0, p.cheb_bias, 0, 1, 0, 1);
+            add_task(b, gr.region_w + (long)lo * C, RC, 1, C, C, C, hi - lo, nullptr, 0,
+                     {g0a, g0b, term(L.dAall + (long)lo * C * F, F, 1, (long)C * F, p.cheb_w1, 1, F, 0, F)});
+            if (lo > 0) add_task(b, gr.region_w, RC, 1, C, C, C, lo, nullptr, 0, {g0a, g0b});
+            if (hi < R) add_task(b, gr.region_w + (long)hi * C, RC, 1, C, C, C, R - hi, nullptr, 0, {g0a, g0b});
             // dW0 = S^T dA0 ; dW1 = sum_{owned r} Wl_r^T dA_r ; db_c = S^T db' ; db_l = db'
             // (both stated transposed, see dV_k above: tgnn.linear.weight rows are R*C floats apart)
             add_task(b, gr.cheb_w0, 1, F, 0, F, C, 1, nullptr, 0, {term(L.dA0, 1, F, 0, L.S, C, 1, 0, C)});

@@ -192,27 +192,30 @@ int launch_small_gemm(const SmallGemm& g, hipStream_t st);
 
 // Several such products in ONE launch (the per-step weight compositions are ~27 tiny dependent-free GEMMs; one
 // launch each would dominate the step at TPIMS size).  out[b][i,j] = init[i] + sum_terms sum_k A[..]*B[..].
-struct SgTerm {
-    const float* A; long sai, sak, sab;
-    const float* B; long sbk, sbj, sbb;
-    int k, batch, sum_batch;     // sum_batch: reduce over `batch` operand pairs; else use the output's batch index
+// (compact: 32-bit strides, 16-bit counts -- a whole batch is passed BY VALUE in the kernel-argument block, 4 KB at most, and the
+// composition backward is one launch of 19 tasks since round 4)
+struct SgTerm {                  // 48 bytes
+    const float* A; const float* B;
+    int sai, sak, sab, sbk, sbj, sbb;
+    int k;                       // sum length (< 0: a stride did not fit 32 bits -- add_task refuses the task)
+    short batch, sum_batch;      // sum_batch: reduce over `batch` operand pairs; else use the output's batch index
 };
-struct SgTask {
-    float* C; long sci, scj, scb;
-    int m, n, nbatch;            // output (nbatch, m, n)
-    const float* init; long init_si;   // optional init[i*init_si + j*init_sj] added to the sum (nullptr: 0; init_sj = 0:
-    long init_sj;                      // the same value for every column)
-    int nterm;
+struct SgTask {                  // 200 bytes
+    float* C; const float* init; // optional init[i*init_si + j*init_sj] added to the sum (nullptr: 0; init_sj = 0: the same value
+    int sci, scj, scb, init_si, init_sj;   // for every column)
+    int m, n;                    // output (nbatch, m, n)
+    short nbatch, nterm;
+    short split, pad_;           // lanes per output element (set by launch_small_gemm_multi: 1 for short sums, 8 for long ones, 0 tiled)
     SgTerm term[3];
-    int split;                   // lanes per output element (set by launch_small_gemm_multi: 1 for short sums, 8 for long ones)
 };
-constexpr int SG_MAX_TASKS = 12;
+constexpr int SG_MAX_TASKS = 19;
 struct SgBatch {
     int ntask;
     int overflow;                // set by add_task when a task did not fit (launch_small_gemm_multi then fails)
     int block_start[SG_MAX_TASKS + 1];
     SgTask task[SG_MAX_TASKS];
 };
+static_assert(sizeof(SgBatch) <= 4000, "SgBatch travels in the kernel-argument block");
 int launch_small_gemm_multi(SgBatch& b, hipStream_t st);
 
 // ---- graph preparation (graph.hip) ---------------------------------------------------------------
