@@ -46,6 +46,10 @@ struct V8 { float v[8]; };
 typedef float f2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ V8 f_sigmoid8(const V8& v, const V8& b) {
     V8 o;
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 2)      // timing-only developer build: no gate arithmetic
+    for (int i = 0; i < 8; ++i) o.v[i] = v.v[i] + b.v[i];
+    return o;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f2_t s = {v.v[2 * i], v.v[2 * i + 1]};
@@ -61,6 +65,10 @@ __device__ __forceinline__ V8 f_sigmoid8(const V8& v, const V8& b) {
 }
 __device__ __forceinline__ V8 f_tanh8(const V8& v, const V8& b) {
     V8 o;
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 2)
+    for (int i = 0; i < 8; ++i) o.v[i] = v.v[i] + b.v[i];
+    return o;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f2_t s = {v.v[2 * i], v.v[2 * i + 1]};
@@ -103,10 +111,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t f_rsrc(const void* p, long byt
 __device__ __forceinline__ bf16x8 f_ldfrag(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 16)     // timing-only developer build: weight fragments are not loaded at all
+__device__ __forceinline__ bf16x8 f_ldw(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("" : "+v"(z) : "v"(voff), "s"(soff));
+    return z;
+}
+#else
+#define f_ldw f_ldfrag
+#endif
 
 constexpr int FT_ROWS = 64;              // rows of a tile
-constexpr int FT_IMG_LD = 36;            // floats per row of a wave's image (its 32 columns + 4)
-constexpr int FT_IMG_ROWS = 16;
+constexpr int FT_IMG_LD = 32;            // floats per row of a wave's image: its 32 columns, no padding -- the 16-byte chunk c of row r
+constexpr int FT_TRACE_SLOTS = 32;       // shader-clock stamps per tile of the developer trace
+constexpr int FT_IMG_ROWS = 16;          //   lies at chunk c ^ ft_par(r) (below): every access pattern of the epilogues is conflict-free
+// Swizzle of a wave's epilogue image.  Three access patterns meet in it: the accumulator rows (ds_write_b32, 32 lanes = one row),
+// the (row, 8 columns) reads / writes of the element-wise work (ds_read_b128 / ds_write_b128: lane = (row l >> 2, chunks 2 (l & 3),
+// 2 (l & 3) + 1)) and the column reads of the per-node sums (ds_read_b32, 32 lanes = one row).  b128 reads are served in the lane
+// groups {0-3, 12-15, 20-27}, ... over 64 banks, i.e. rows {0, 3, 5, 6}, {1, 2, 4, 7} (+8): two rows of equal parity in a group
+// must use different chunk parities; b128 writes in groups of 8 lanes = rows {2g, 2g + 1} over 32 banks: the two rows must differ
+// too.  par(r) = (r ^ (r >> 2)) & 1 satisfies both (0 1 0 1 1 0 1 0 for rows 0..7).
+__device__ __forceinline__ constexpr int ft_par(int r) { return (r ^ (r >> 2)) & 1; }
 
 }  // namespace
 
@@ -115,9 +140,20 @@ struct FusedFwdLds {
     static constexpr int PLANE_B = FT_ROWS * 32;                 // one 16-k block of 64 rows
     static constexpr int OPER_B = (C / 16) * PLANE_B;            // h (or q) of the tile as an A operand
     static constexpr int IMG_OFF = 2 * OPER_B;                   // four wave-private 16-row fp32 images
-    static constexpr int BYTES = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
+    static constexpr int BIAS_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;   // b' (C), [cz | cr] (2C), ch (C): fp32, copied once per workgroup
+    static constexpr int BYTES = BIAS_OFF + 4 * C * 4;
 };
 
+// Persistent: a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the grid is two workgroups per CU) and requests
+// the x / L~ x rows, the region ids and the first weight fragments of its NEXT tile before the last epilogue of the current one:
+// a freshly dispatched workgroup waited ~9.5 k cycles (of a tile's 70 k) for those first loads -- HBM latency under load, which
+// nothing else of that workgroup could hide.  The biases live in LDS (4 KB, copied once): as global loads issued at the end of a
+// K loop they sat in front of every epilogue's first round (one L2 round trip each, eight per tile).
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 32)     // timing-only developer build: no activation stores
+#define FT_STORE16(v, ...) asm volatile("" :: "v"(v))
+#else
+#define FT_STORE16(...) __builtin_amdgcn_raw_buffer_store_b128(__VA_ARGS__)
+#endif
 template <int C, int F>
 __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     static_assert(C % 128 == 0 && F % 16 == 0, "tile shapes");
@@ -126,115 +162,167 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char flds[];
     char* Hp = flds;
     char* Qp = flds + L::OPER_B;
+    float* biasl = reinterpret_cast<float*>(flds + L::BIAS_OFF);
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: fragment addresses go into scalar offsets
-    const long m0 = (long)blockIdx.x * FT_ROWS;
-    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
-    const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;     // N * T < 2^31 (host-checked): 32-bit row arithmetic
-    const unsigned node0 = mrow0 / uT;
-    const int t0 = (int)(mrow0 - node0 * uT);                    // period of the tile's first row (wave-uniform)
+    const unsigned uT = (unsigned)a.T;                           // N * T < 2^31 (host-checked): 32-bit row arithmetic
+    const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
     // developer trace (REGT_FUSED_TRACE=1, tools/fused_trace.py): shader-clock stamps of thread 0 at the phase boundaries
-#define FT_MARK(i) do { if (a.trace && tid == 0) a.trace[8L * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
-    FT_MARK(0);
-
-    // ---- descriptors: the tile's rows of every activation array (rows past the end are out of range: loads return 0, stores are dropped)
-    const __amdgpu_buffer_rsrc_t sX = f_rsrc(reinterpret_cast<const char*>(a.X) + m0 * F * 2, (long)nvalid * F * 2);
-    const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
-    const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
+    // (-DREGT_FUSED_FINE, a developer build: FT_FINE stamps inside the phases as well -- slots 8 .. 31 of the tile's record)
+#define FT_MARK(i) do { if (a.trace && tid == 0) a.trace[(long)FT_TRACE_SLOTS * tile + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+#ifdef REGT_FUSED_FINE
+#define FT_FINE(i) FT_MARK(i)
+#else
+#define FT_FINE(i) do {} while (0)
+#endif
     // (timing-only switches, REGT_FUSED_DBG: bit 0 = zero-record store descriptors: every activation store is dropped by the range
-    // check; bit 1 = zero-record weight descriptors: fragment loads return 0 without traffic -- cdna_hip_programming.md section 7;
-    // bit 2 = no per-node column sums at all, bit 3 = column sums without their atomic adds)
+    // check; bit 1 = zero-record weight descriptors: fragment loads return 0 without traffic -- cdna_hip_programming.md section 7)
     const int st_on = (a.dbg & 1) ? 0 : 1, w_on = (a.dbg & 2) ? 0 : 1;
-    const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
-    const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
-    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
-    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4 * st_on);
     // A-fragment offsets of the K = F operands: lane (lr, lh) holds k = 8 lh .. 8 lh + 7 of row 32 mi + lr of a 16-k block
     const int afo = lr * F * 2 + lh * 16;
-    // Everything phase 0 needs that does not depend on the region table is requested first (x, A_hat x, the A0 fragments): the
-    // row / region tables are computed while those loads fly.  Vector-memory operations retire in issue order (stores included
-    // -- gfx9 has one counter), so a load issued BEHIND an epilogue's stores only returns once those stores are acknowledged;
-    // hence the rule of this kernel: the fragments of the NEXT K loop are requested before the current epilogue stores.
-    bf16x8 axf[2][KBF], xf[2][KBF], lf[2][KBF], b0[2][KBF], b1[2][KBF];    // b0 / b1: fragments of A0 ([0]) and A_region ([1]) of column tile 0 / 1
-    {
-        const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
+
+    // ---- what a tile needs first, requested one tile ahead: x and L~ x rows as A fragments (L~ x unmasked: rows of another region
+    //      than the tile's first are zeroed in registers) and the region of each lane's two fragment rows -- the HBM part; the
+    //      weight fragments of phase 0 (L2) are requested at the top of the tile.  Vector-memory operations retire in issue order (stores included -- gfx9 has one counter), so a load
+    //      issued BEHIND an epilogue's stores only returns once those stores are acknowledged; hence the rule of this kernel: what
+    //      the NEXT K loop (or tile) needs is requested before the current epilogue stores.
+    bf16x8 xf[2][KBF], lf[2][KBF];
+    int rg_a, rg_b, rg0;                                         // region of rows lr / 32 + lr (-1: past the end) / of the tile's first row
+    auto request_tile = [&](long tile, int rg_first) {
+        const long m0 = tile * FT_ROWS;
+        const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+        const unsigned mrow0 = (unsigned)m0;
+        const __amdgpu_buffer_rsrc_t sX = f_rsrc(reinterpret_cast<const char*>(a.X) + m0 * F * 2, (long)nvalid * F * 2);
+        const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) {
             xf[0][kb] = f_ldfrag(sX, afo, kb * 32);
             xf[1][kb] = f_ldfrag(sX, afo + 32 * F * 2, kb * 32);
         }
-        // (L~ x rows too, unmasked: waiting for the region lookup first would put two memory latencies in series; rows of
-        // another region than the tile's first are zeroed in registers below)
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) {
             lf[0][kb] = f_ldfrag(sLX, afo, kb * 32);
             lf[1][kb] = f_ldfrag(sLX, afo + 32 * F * 2, kb * 32);
         }
+        // every lane looks up the region of ITS two fragment rows (32 mi + lr); the waves vote on "more than one region in this
+        // tile" (rare: a tile that straddles a region boundary) where the rows of other regions are masked
+        auto region_of = [&](int r) { return r < nvalid ? (a.node_region ? a.node_region[(mrow0 + (unsigned)r) / uT] : 0) : -1; };
+        rg_a = region_of(lr);
+        rg_b = region_of(32 + lr);
+        rg0 = rg_first;
+    };
+    // (the region of a tile's first row through the scalar cache, one tile ahead of the fragment requests that depend on it)
+    auto first_region = [&](long tile) { return a.node_region ? a.node_region[(unsigned)(tile * FT_ROWS) / uT] : 0; };
+    long tile = blockIdx.x;
+    request_tile(tile, first_region(tile));
+    for (int i = tid; i < 4 * C; i += 256) biasl[i] = i < C ? a.bprime[i] : (i < 3 * C ? a.czr[i - C] : a.ch[i - 3 * C]);
+
+    // Epilogue geometry.  Every wave transposes its OWN 64 x 32 accumulator strip through a wave-private 16-row image, so an
+    // epilogue needs no workgroup barrier at all (LDS operations of one wave execute in order): round rnd = rows 16 rnd ..
+    // 16 rnd + 15 of the tile; lane = (row lane >> 2, columns 8 (lane & 3) .. + 7 of the wave's 32) = 16 bytes of a bf16 array.
+    // The same lane owns the same (row, columns) in the Z and in the candidate epilogue, which is what lets Z stay in registers.
+    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
+    const int er0 = lane >> 2, ec0 = 32 * w + 8 * (lane & 3);
+    int er = er0, ec = ec0;
+    // image addresses (floats; swizzle: ft_par above): an accumulator register of lane (lr, lh) is row (q & 3) + 8 (q >> 2) + 4 lh of
+    // the round, whose parity is (q & 1) ^ lh; the lane's 8 epilogue columns are chunks 2 (lane & 3), 2 (lane & 3) + 1 of row er
+    const int st_even = 4 * lh * FT_IMG_LD + (lr ^ (4 * lh)), st_odd = 4 * lh * FT_IMG_LD + (lr ^ (4 * (lh ^ 1)));
+    const int e_lo = er * FT_IMG_LD + 4 * ((2 * (lane & 3)) ^ ft_par(er)), e_hi = er * FT_IMG_LD + 4 * ((2 * (lane & 3) + 1) ^ ft_par(er));
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 4)      // timing-only developer build: no transposition through LDS
+    V8 abl_v;
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {
+        const int mi = rnd >> 1, rd = rnd & 1;
 #pragma unroll
-        for (int kb = 0; kb < KBF; ++kb) b0[0][kb] = f_ldfrag(sA0, lane * 16, (w * KBF + kb) * 1024);
+        for (int q = 0; q < 8; ++q) abl_v.v[q] = mi ? acc[1][8 * rd + q] : acc[0][8 * rd + q];
+    };
+    auto img8 = [&]() { return abl_v; };
+#else
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {          // accumulators of round rnd -> the wave's image
+        const int mi = rnd >> 1, rd = rnd & 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
+            imgw[((q & 3) + 8 * (q >> 2)) * FT_IMG_LD + ((q & 1) ? st_odd : st_even)] = mi ? acc[1][reg] : acc[0][reg];
+        }
+    };
+    auto img8 = [&]() {
+        const float4 lo = *reinterpret_cast<const float4*>(imgw + e_lo), hi = *reinterpret_cast<const float4*>(imgw + e_hi);
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+#endif
+    auto bias8 = [&](int i) {                                    // (i: offset into [b' | cz | cr | ch])
+        const float4 lo = *reinterpret_cast<const float4*>(biasl + i), hi = *reinterpret_cast<const float4*>(biasl + i + 4);
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    // the 16 bytes of (row, columns c .. c + 7) inside an operand's planes
+    auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
+    __syncthreads();                                            // the biases are in LDS
+
+#pragma unroll 1
+    for (; tile < tiles; tile += gridDim.x) {
+    // (opaque per tile: hoisted out of the tile loop, the ~30 global / plane offsets derived from them stay live through every K loop)
+    asm volatile("" : "+v"(er), "+v"(ec));
+    const long m0 = tile * FT_ROWS;
+    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+    const unsigned mrow0 = (unsigned)m0;
+    const unsigned node0 = mrow0 / uT;
+    const int t0 = (int)(mrow0 - node0 * uT);                    // period of the tile's first row (wave-uniform)
+    // the tile after this one (clamped: the last round requests the last tile once more instead of branching around the loads)
+    const long tnext = tile + gridDim.x < tiles ? tile + gridDim.x : tiles - 1;
+    const int rg_next = first_region(tnext);
+    // Node boundaries of the tile as row masks (bit r = row r; all scalar): a.pmask has the bits k T < 64 (the host's division), so
+    // the rows that START a node are pmask shifted to the first such row; a row ENDS a node (inside this tile) when the next one
+    // starts one or it is the tile's last row; the ends whose sum is only a part of the node's go to memory as atomic adds: the
+    // first one when the tile starts inside a node, the last one when the tile ends inside one.
+    const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+    const int s0 = t0 == 0 ? 0 : a.T - t0;
+    const unsigned long long smask = s0 < 64 ? (a.pmask << s0) & vmask : 0ull;
+    const unsigned long long emask = ((smask >> 1) | (1ull << (nvalid - 1))) & vmask;
+    const unsigned long long amask = (t0 != 0 ? emask & (0ull - emask) : 0ull) | (((unsigned)(t0 + nvalid) % uT) != 0 ? 1ull << (nvalid - 1) : 0ull);
+    FT_MARK(0);
+
+    // ---- descriptors: the tile's rows of every activation array (rows past the end are out of range: loads return 0, stores are dropped)
+    const __amdgpu_buffer_rsrc_t sLX = f_rsrc(reinterpret_cast<const char*>(a.LX) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sAX = f_rsrc(reinterpret_cast<const char*>(a.AX) + m0 * F * 2, (long)nvalid * F * 2);
+    const __amdgpu_buffer_rsrc_t sh = f_rsrc(reinterpret_cast<char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sq = f_rsrc(reinterpret_cast<char*>(a.q) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2 * st_on);
+    const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4 * st_on);
+    bf16x8 axf[2][KBF], b0[2][KBF], b1[2][KBF];                  // A_hat x fragments; A0 ([0]) / A_region ([1]) fragments of column tile 0 / 1
+    const int rgt = rg0, rga = rg_a, rgb = rg_b;                 // (this tile's; the loop-carried set is refilled further down)
+    {
+        const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
+        const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rgt * a.ar_stride, (long)C * F * 2);
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) b0[0][kb] = f_ldw(sA0, lane * 16, (w * KBF + kb) * 1024);
+#pragma unroll
+        for (int kb = 0; kb < KBF; ++kb) b0[1][kb] = f_ldw(sAr, lane * 16, (w * KBF + kb) * 1024);
     }
-    // Row bookkeeping without tables or barriers: every lane looks up the region of ITS two fragment rows (32 mi + lr), every
-    // wave votes on "more than one region in the tile" (rare: a tile that straddles a region boundary), node boundaries and
-    // periods of the rows are wave-uniform scalars (t0 + r) mod T.
-    auto region_of = [&](int r) { return r < nvalid ? (a.node_region ? a.node_region[(mrow0 + (unsigned)r) / uT] : 0) : -1; };
-    const int rg_a = region_of(lr), rg_b = region_of(32 + lr);
-    const int rg0 = __builtin_amdgcn_readfirstlane(rg_a);
-    const bool multi = __ballot((rg_a >= 0 && rg_a != rg0) || (rg_b >= 0 && rg_b != rg0)) != 0;
     float ptr_[4];                                               // attention probability of the lane's epilogue row of each round
 #pragma unroll
     for (int rnd = 0; rnd < 4; ++rnd) {
         const unsigned m = mrow0 + 16 * rnd + (lane >> 2);
         ptr_[rnd] = a.probs[m - (m / uT) * uT];
     }
-    {
-        const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
+    const bool multi = __ballot((rga >= 0 && rga != rgt) || (rgb >= 0 && rgb != rgt)) != 0;
+    if (multi) {                                                 // rare: rows of the tile's other regions contribute to THEIR region's pass
+        const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int kb = 0; kb < KBF; ++kb) b0[1][kb] = f_ldfrag(sAr, lane * 16, (w * KBF + kb) * 1024);
-        if (multi) {                                             // rare: rows of the tile's other regions contribute to THEIR region's pass
-            const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int kb = 0; kb < KBF; ++kb) {
-                lf[0][kb] = rg_a == rg0 ? lf[0][kb] : zero;
-                lf[1][kb] = rg_b == rg0 ? lf[1][kb] : zero;
-            }
+        for (int kb = 0; kb < KBF; ++kb) {
+            lf[0][kb] = rga == rgt ? lf[0][kb] : zero;
+            lf[1][kb] = rgb == rgt ? lf[1][kb] : zero;
         }
     }
     FT_MARK(1);
 
-    // Epilogue geometry.  Every wave transposes its OWN 64 x 32 accumulator strip through a wave-private 16-row image, so an
-    // epilogue needs no workgroup barrier at all (LDS operations of one wave execute in order): round rnd = rows 16 rnd ..
-    // 16 rnd + 15 of the tile; lane = (row lane >> 2, columns 8 (lane & 3) .. + 7 of the wave's 32) = 16 bytes of a bf16 array.
-    // The same lane owns the same (row, columns) in the Z and in the candidate epilogue, which is what lets Z stay in registers.
-    // The only barriers left are the two hand-overs of the h and q planes between the waves.
-    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
-    const int er = lane >> 2, ec = 32 * w + 8 * (lane & 3);
-    auto stage = [&](const f32x16 (&acc)[2], int rnd) {          // accumulators of round rnd -> the wave's image
-        const int mi = rnd >> 1, rd = rnd & 1;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
-            imgw[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + lr] = mi ? acc[1][reg] : acc[0][reg];
-        }
-    };
-    auto img8 = [&]() {
-        const float4* p = reinterpret_cast<const float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
-        const float4 lo = p[0], hi = p[1];
-        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-    };
-    auto bias8 = [&](const float* b) {
-        const float4 lo = *reinterpret_cast<const float4*>(b), hi = *reinterpret_cast<const float4*>(b + 4);
-        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-    };
-    // the 16 bytes of (row, columns c .. c + 7) inside an operand's planes
-    auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
     // B fragments of one K = C + F loop: W (C x C, column block nb) and G (column block nbg of a (rows x F) composed weight)
     bf16x8 bw[KBC], bg[KBF];
     auto issue_b = [&](const void* Wf, int nb, const void* Gf, int nbg) {
         const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2 * w_on), sG = f_rsrc(Gf, (long)0x7ffffff0 * w_on);
 #pragma unroll
-        for (int kb = 0; kb < KBC; ++kb) bw[kb] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
+        for (int kb = 0; kb < KBC; ++kb) bw[kb] = f_ldw(sW, lane * 16, (nb * KBC + kb) * 1024);
 #pragma unroll
-        for (int kb = 0; kb < KBF; ++kb) bg[kb] = f_ldfrag(sG, lane * 16, (nbg * KBF + kb) * 1024);
+        for (int kb = 0; kb < KBF; ++kb) bg[kb] = f_ldw(sG, lane * 16, (nbg * KBF + kb) * 1024);
     };
     // acc = P (planes, K = C) x W^T + (A_hat x) x G^T with the fragments requested by the last issue_b
     auto kloop = [&](f32x16 (&acc)[2], const char* P) {
@@ -263,14 +351,22 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
                 fa[kb + AHEAD][1] = *reinterpret_cast<const bf16x8*>(pa1 + (kb + AHEAD) * L::PLANE_B);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 1)      // timing-only developer build: no matrix instructions (operands kept alive)
+            asm volatile("" :: "v"(fa[kb][0]), "v"(fa[kb][1]), "v"(bw[kb]));
+#else
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], bw[kb], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], bw[kb], acc[1], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int kb = 0; kb < KBF; ++kb) {
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 1)
+            asm volatile("" :: "v"(axf[0][kb]), "v"(axf[1][kb]), "v"(bg[kb]));
+#else
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axf[0][kb], bg[kb], acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axf[1][kb], bg[kb], acc[1], 0, 0, 0);
+#endif
         }
     };
 
@@ -285,11 +381,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         static_assert(NT == 2, "phase 0 double-buffers the fragments of two column tiles");
         if (j == 0) {           // the fragments of column tile 1 are requested before tile 0's epilogue stores
             const __amdgpu_buffer_rsrc_t sA0 = f_rsrc(a.A0f, (long)C * F * 2);
-            const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg0 * a.ar_stride, (long)C * F * 2);
+            const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rgt * a.ar_stride, (long)C * F * 2);
 #pragma unroll
             for (int kb = 0; kb < KBF; ++kb) {
-                b1[0][kb] = f_ldfrag(sA0, lane * 16, ((4 + w) * KBF + kb) * 1024);
-                b1[1][kb] = f_ldfrag(sAr, lane * 16, ((4 + w) * KBF + kb) * 1024);
+                b1[0][kb] = f_ldw(sA0, lane * 16, ((4 + w) * KBF + kb) * 1024);
+                b1[1][kb] = f_ldw(sAr, lane * 16, ((4 + w) * KBF + kb) * 1024);
             }
         }
 #pragma unroll
@@ -303,16 +399,16 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[1][kb], j ? b1[1][kb] : b0[1][kb], acc[1], 0, 0, 0);
         }
         // further regions of the tile (rare), in order of first appearance by row: rows of other regions contribute zeros
-        bool done_a = rg_a < 0 || rg_a == rg0, done_b = rg_b < 0 || rg_b == rg0;
+        bool done_a = rga < 0 || rga == rgt, done_b = rgb < 0 || rgb == rgt;
 #pragma unroll 1
         while (multi) {
             const unsigned long long ma = __ballot(!done_a), mb = __ballot(!done_b);
             if (!(ma | mb)) break;
-            const int rg = ma ? __builtin_amdgcn_readlane(rg_a, __builtin_ctzll(ma)) : __builtin_amdgcn_readlane(rg_b, __builtin_ctzll(mb));
-            done_a = done_a || rg_a == rg;
-            done_b = done_b || rg_b == rg;
+            const int rg = ma ? __builtin_amdgcn_readlane(rga, __builtin_ctzll(ma)) : __builtin_amdgcn_readlane(rgb, __builtin_ctzll(mb));
+            done_a = done_a || rga == rg;
+            done_b = done_b || rgb == rg;
             const __amdgpu_buffer_rsrc_t sAr = f_rsrc(reinterpret_cast<const char*>(a.Aallf) + (long)rg * a.ar_stride, (long)C * F * 2);
-            const int o0 = rg_a == rg ? afo : 0x7ffffff0, o1 = rg_b == rg ? afo + 32 * F * 2 : 0x7ffffff0;
+            const int o0 = rga == rg ? afo : 0x7ffffff0, o1 = rgb == rg ? afo + 32 * F * 2 : 0x7ffffff0;
             bf16x8 b[KBF], x[2][KBF];
 #pragma unroll
             for (int kb = 0; kb < KBF; ++kb) {
@@ -333,12 +429,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < KBF; ++kb) axf[mi][kb] = f_ldfrag(sAX, afo + mi * 32 * F * 2, kb * 32);
         }
-        const V8 b = bias8(a.bprime + 128 * j + ec);
+        FT_FINE(8 + 2 * j);
+        // (every wave is done with the planes of the workgroup's previous tile: its Z / candidate K loops read them)
+        if (j == 0) __syncthreads();
+        const V8 b = bias8(128 * j + ec);
         const float ns = a.act_lrelu ? a.slope : 1.0f;
         // (tried in round 4 and measured no faster: staging and reading back round rnd + 1 before round rnd is consumed -- the LDS
         // round trip under the arithmetic of the previous round -- 1.75 vs 1.70-1.72 ms; packed two-lane arithmetic in the gate
-        // epilogues, f_sigmoid8 / f_tanh8: 9 % fewer vector instructions, same time.  The tile's 71 k cycles are dependency
-        // latency at two waves per SIMD, not instruction count: tools/fused_trace.py)
+        // epilogues, f_sigmoid8 / f_tanh8: 9 % fewer vector instructions, same time)
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
@@ -348,12 +446,14 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             for (int i = 0; i < 8; ++i) { const float s = v.v[i] + b.v[i]; o.v[i] = s > 0.f ? s : s * ns; }
             const u32x4_t pk = f_pack8(o);
             const int row = 16 * rnd + er, c = 128 * j + ec;
-            __builtin_amdgcn_raw_buffer_store_b128(pk, sh, (row * C + c) * 2, 0, 0);
+            FT_STORE16(pk, sh, (row * C + c) * 2, 0, 0);
             *reinterpret_cast<u32x4_t*>(Hp + plane_off(row, c)) = pk;
         }
+        FT_FINE(9 + 2 * j);
     }
     FT_MARK(2);
     __syncthreads();                                            // h planes complete
+    FT_FINE(12);
 
     // ---- phase 1: reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R -> global + q planes ---------------------------
 #pragma unroll
@@ -362,9 +462,11 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         kloop(acc, Hp);
         if (j + 1 < NT) issue_b(a.Urf, 4 * (j + 1) + w, a.Gzrf, C / 32 + 4 * (j + 1) + w);
         else issue_b(a.Uzf, w, a.Gzrf, w);                                  // update gate, column tile 0
-        const V8 b = bias8(a.czr + C + 128 * j + ec);
+        const V8 b = bias8(2 * C + 128 * j + ec);
+        FT_FINE(13 + 5 * j);
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
+            if (rnd) FT_FINE(13 + 5 * j + rnd);
             stage(acc, rnd);
             const V8 v = img8();
             const int row = 16 * rnd + er, c = 128 * j + ec;
@@ -373,14 +475,16 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             V8 qv;
 #pragma unroll
             for (int i = 0; i < 8; ++i) qv.v[i] = hv.v[i] * g.v[i];
-            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(g), sZR, (row * 2 * C + C + c) * 2, 0, 0);
+            FT_STORE16(f_pack8(g), sZR, (row * 2 * C + C + c) * 2, 0, 0);
             const u32x4_t pq = f_pack8(qv);
-            __builtin_amdgcn_raw_buffer_store_b128(pq, sq, (row * C + c) * 2, 0, 0);
+            FT_STORE16(pq, sq, (row * C + c) * 2, 0, 0);
             *reinterpret_cast<u32x4_t*>(Qp + plane_off(row, c)) = pq;
         }
+        FT_FINE(17 + 5 * j);
     }
     FT_MARK(3);
     __syncthreads();                                            // q planes complete
+    FT_FINE(23);
 
     // ---- phases 2 + 3 per column tile: update gate Z (kept in registers), candidate H~, blend, sum over the node's periods ---
 #pragma unroll
@@ -389,27 +493,38 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         {
             f32x16 acc[2];
             kloop(acc, Hp);
+            if (j == 0) FT_FINE(24);
             issue_b(a.Uhf, 4 * j + w, a.Ghf, 4 * j + w);                      // candidate, same column tile
-            const V8 b = bias8(a.czr + 128 * j + ec);
+            const V8 b = bias8(C + 128 * j + ec);
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
                 stage(acc, rnd);
                 const V8 v = img8();
                 const V8 g = f_sigmoid8(v, b);
                 zk[rnd] = f_pack8(g);
-                __builtin_amdgcn_raw_buffer_store_b128(zk[rnd], sZR, ((16 * rnd + er) * 2 * C + 128 * j + ec) * 2, 0, 0);
+                FT_STORE16(zk[rnd], sZR, ((16 * rnd + er) * 2 * C + 128 * j + ec) * 2, 0, 0);
             }
         }
         FT_MARK(4 + 2 * j);
         f32x16 acc[2];
         kloop(acc, Qp);
         if (j + 1 < NT) issue_b(a.Uzf, 4 * (j + 1) + w, a.Gzrf, 4 * (j + 1) + w);
-        const V8 b = bias8(a.ch + 128 * j + ec);
-        int nd = 0, tc = t0;             // lanes 0..31: running sum of column 32 w + lane over the rows of node node0 + nd
-        float csum = 0.f;                //   (nd, tc = period of the next row: wave-uniform)
-        float* oh = a.OH + (long)node0 * C + 128 * j + 32 * w + lr;
+        else request_tile(tnext, rg_next);                                  // the next tile's first operands
+        const V8 b = bias8(3 * C + 128 * j + ec);
+        if (j == 0) FT_FINE(25);
+        // Per-node sums of the blended rows (the attention-weighted sum over the periods).  Every lane keeps ONE running column sum
+        // (column 32 w + lr of the tile; lanes 32..63 duplicate lanes 0..31 and store nothing) over the tile's rows in row order;
+        // node boundaries are wave-uniform bit masks of the tile's rows (smask / emask / amask above): a row that starts a node
+        // multiplies the carried sum by 0 (fma(c, 0, v) = v, fma(c, 1, v) = c + v: the sums are exactly those of a plain `c += v`
+        // chain per node), a row that ends one hands the sum over.
+        float csum = 0.f;
+        int ohs = 0;                     // byte offset of the current node's row of OH behind the tile's first node (scalar)
+        const long ohcol = (long)node0 * C + 128 * j + 32 * w;
+        const __amdgpu_buffer_rsrc_t sOH = f_rsrc(a.OH + ohcol, (a.nodes * C - ohcol) * 4);
+        const int ohv = lane < 32 ? lr * 4 : 0x7ffffff0;       // (out of range: dropped)
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
+            if (j == 0 && rnd) FT_FINE(25 + rnd);
             stage(acc, rnd);
             const V8 v = img8();
             const int row = 16 * rnd + er, c = 128 * j + ec;
@@ -420,43 +535,49 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
             V8 bl;
 #pragma unroll
             for (int i = 0; i < 8; ++i) bl.v[i] = __fmul_rn(pt, gru_blend(Zv.v[i], hv.v[i], ht.v[i]));
-            __builtin_amdgcn_raw_buffer_store_b128(f_pack8(ht), sHt, (row * C + c) * 2, 0, 0);
-            float4* p = reinterpret_cast<float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
-            p[0] = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
-            p[1] = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
-            if (lh == 0 && !(a.dbg & 4)) {
+            FT_STORE16(f_pack8(ht), sHt, (row * C + c) * 2, 0, 0);
+            *reinterpret_cast<float4*>(imgw + e_lo) = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
+            *reinterpret_cast<float4*>(imgw + e_hi) = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 8)      // timing-only developer build: no per-node sums
+            continue;
+#endif
+            float cv[16];
 #pragma unroll
-                for (int r8 = 0; r8 < FT_IMG_ROWS; r8 += 8) {          // LDS reads of 8 rows first, then the serial chain on registers
-                    float cv[8];
+            for (int r = 0; r < 16; ++r) cv[r] = imgw[r * FT_IMG_LD + (ft_par(r) ? lr ^ 4 : lr)];
+            // (the masks are made opaque per round: left alone, hipcc shares the 128 bit tests of the two column tiles through
+            // spilled scalar registers; the 0 / 1 factor is selected on the scalar unit: as a float select it becomes a v_cndmask)
+            unsigned sm = (unsigned)(smask >> (16 * rnd)), em = (unsigned)(emask >> (16 * rnd)), am = (unsigned)(amask >> (16 * rnd));
+            asm volatile("" : "+s"(sm), "+s"(em), "+s"(am));
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) cv[r] = imgw[(r8 + r) * FT_IMG_LD + lr];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        const int row = 16 * rnd + r8 + r;             // (all of this control flow is wave-uniform)
-                        if (row < nvalid) {
-                            if (tc == 0 && row > 0) {                  // the row starts a new node: hand the finished one over
-                                // (a node that began in this tile has no rows elsewhere: a plain store into the zeroed array;
-                                // only the tile's first node can continue a node of the previous tile)
-                                if (a.dbg & 8) {}
-                                else if (nd > 0 || t0 == 0) oh[(long)nd * C] = csum;
-                                else atomicAdd(oh, csum);
-                                ++nd;
-                                csum = 0.f;
-                            }
-                            csum += cv[r];
-                            tc = tc + 1 == a.T ? 0 : tc + 1;
-                        }
-                    }
+            for (int r = 0; r < 16; ++r) {
+                float keep;
+                asm volatile("s_bitcmp1_b32 %1, %2\n\ts_cselect_b32 %0, 0, 1.0" : "=s"(keep) : "s"(sm), "n"(r) : "scc");
+                csum = fmaf(csum, keep, cv[r]);
+                if ((em >> r) & 1u) {                                   // (wave-uniform, one row in T)
+                    // a node whose rows all lie in this tile has no rows elsewhere: a plain store into the zeroed array; only the
+                    // tile's first / last node can continue in a neighbouring tile (two addends at most: still bit-reproducible).
+                    // Both instructions are issued, the one that does not apply with an out-of-range offset (no branch).
+                    const bool part = (am >> r) & 1u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(csum), sOH, ohv, part ? 0x7ffffff0 : ohs, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(csum, sOH, ohv, part ? ohs : 0x7ffffff0, 0);
+                    ohs += C * 4;
                 }
             }
         }
-        if (lh == 0 && !(a.dbg & 12)) {          // the last node: complete iff it began here and its last period is the tile's last row
-            if (tc == 0 && (nd > 0 || t0 == 0)) oh[(long)nd * C] = csum;
-            else atomicAdd(oh + (long)nd * C, csum);
-        }
         FT_MARK(5 + 2 * j);
     }
+    }
 #undef FT_MARK
+#undef FT_FINE
+}
+
+static int fused_cus() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 static long* g_fused_trace = nullptr;
@@ -466,11 +587,11 @@ static long* fused_trace_buffer(int which, long tiles) {
     static int tr = -1;
     if (tr < 0) { const char* e = getenv("REGT_FUSED_TRACE"); tr = e ? atoi(e) : 0; }
     if (tr != which) return nullptr;
-    if (!g_fused_trace || g_fused_trace_n < 8 * tiles) {
+    if (!g_fused_trace || g_fused_trace_n < FT_TRACE_SLOTS * tiles) {
         if (g_fused_trace) (void)hipFree(g_fused_trace);
         g_fused_trace = nullptr;
-        if (hipMalloc(&g_fused_trace, 8 * tiles * sizeof(long)) != hipSuccess) return nullptr;
-        g_fused_trace_n = 8 * tiles;
+        if (hipMalloc(&g_fused_trace, FT_TRACE_SLOTS * tiles * sizeof(long)) != hipSuccess) return nullptr;
+        g_fused_trace_n = FT_TRACE_SLOTS * tiles;
     }
     return g_fused_trace;
 }
@@ -513,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;
     const unsigned node0 = mrow0 / uT;
     const long nodes = a.M / a.T;
-#define FB_MARK(i) do { if (a.trace && tid == 0) a.trace[8L * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+#define FB_MARK(i) do { if (a.trace && tid == 0) a.trace[(long)FT_TRACE_SLOTS * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
     FB_MARK(0);
     // the tile's rows of every activation array; dOH from the tile's first node on (rows past the end read zeros, stores are dropped)
     const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<const char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
@@ -795,6 +916,10 @@ int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
     if (dbg < 0) { const char* e = getenv("REGT_FUSED_DBG"); dbg = e ? atoi(e) : 0; }
     FusedFwdArgs a = a_;
     a.dbg = dbg;
+    REGT_CHECK_ARG(a.M % a.T == 0, "fused forward: M = %ld rows are no whole number of T = %d periods", a.M, a.T);
+    a.nodes = a.M / a.T;
+    a.pmask = 0;
+    for (int r = 0; r < 64; r += a.T) a.pmask |= 1ull << r;
     a.trace = fused_trace_buffer(1, (a_.M + FT_ROWS - 1) / FT_ROWS);
     REGT_CHECK_ARG(fused_forward_ok(C, F), "fused forward: built for C = 256, F = 32 or 64 (got C = %d, F = %d)", C, F);
     const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
@@ -806,8 +931,11 @@ int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
         REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_kernel<256, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
         attr_done = true;
     }
-    if (F == 64) hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
-    else hipLaunchKernelGGL((fused_fwd_kernel<256, 32>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    // persistent: two workgroups per CU (what LDS and registers admit), each walks its tiles with a stride of the grid
+    const long slots = 2L * fused_cus();
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    if (F == 64) hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3(grid), dim3(256), L::BYTES, st, a);
+    else hipLaunchKernelGGL((fused_fwd_kernel<256, 32>), dim3(grid), dim3(256), L::BYTES, st, a);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

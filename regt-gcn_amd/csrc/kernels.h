@@ -261,6 +261,8 @@ struct FusedFwdArgs {
     void *h, *ZR, *q, *Ht;                    // bf16 outputs: (M x C), (M x 2C) = [Z | R], (M x C), (M x C)
     float* OH;                                // (nodes x C) fp32, zero-initialised: the attention-weighted hidden state
     long M; int T; float slope; int act_lrelu;
+    long nodes;                               // M / T                                            } filled in by launch_fused_forward
+    unsigned long long pmask;                 // bit k T for every k T < 64 (rows that start a node) }
     int dbg;                                  // timing-only switches (REGT_FUSED_DBG, fused.hip); 0 in normal operation
     long* trace;                              // developer trace buffer (REGT_FUSED_TRACE) or nullptr
 };

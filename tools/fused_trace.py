@@ -25,9 +25,11 @@ for _ in range(3):
             model.forward_prepared(x, graph)
 torch.cuda.synchronize()
 tiles = (n * t + 63) // 64
-buf = (ctypes.c_int64 * (8 * tiles))()
-got = lib.regt_debug_trace(buf, 8 * tiles)
-a = np.frombuffer(buf, dtype=np.int64)[:got].reshape(-1, 8)
+SLOTS = 32
+buf = (ctypes.c_int64 * (SLOTS * tiles))()
+got = lib.regt_debug_trace(buf, SLOTS * tiles)
+full = np.frombuffer(buf, dtype=np.int64)[:got].reshape(-1, SLOTS)
+a = full[:, :8]
 d = np.diff(a, axis=1)
 names = ["tables", "h (2 tiles)", "R, q (2 tiles)", "Z_0", "cand_0", "Z_1", "cand_1"]
 if BWD:
@@ -41,3 +43,17 @@ if BWD:
     d = d[:, :6]
     names = names[:6]
 print(f"  {'tile total':16s} {tot.mean():9.0f} {np.median(tot):9.0f} {np.percentile(tot, 90):9.0f}")
+
+if not BWD and full[:, 8:].any():      # a -DREGT_FUSED_FINE build: stamps inside the phases (fused.hip FT_FINE)
+    f = full
+    def seg(name, i, j):
+        dd = f[:, j] - f[:, i]
+        print(f"  {name:34s} {dd.mean():9.0f} {np.median(dd):9.0f} {np.percentile(dd, 90):9.0f}")
+    print("fine stamps (cycles: mean / median / p90):")
+    seg("h: wait + MFMAs, tile 0", 1, 8); seg("h: epilogue 0 (4 rounds)", 8, 9); seg("h: MFMAs tile 1 (+ issue)", 9, 10); seg("h: epilogue 1", 10, 11)
+    seg("barrier h", 2, 12)
+    seg("R: K loop 0", 12, 13); seg("R: round 0", 13, 14); seg("R: round 1", 14, 15); seg("R: round 2", 15, 16); seg("R: round 3", 16, 17)
+    seg("R: K loop 1", 17, 18); seg("R: epilogue 1", 18, 22)
+    seg("barrier q", 3, 23)
+    seg("Z0: K loop", 23, 24); seg("Z0: epilogue", 24, 4); seg("cand0: K loop", 4, 25)
+    seg("cand0: round 0", 25, 26); seg("cand0: round 1", 26, 27); seg("cand0: round 2", 27, 28); seg("cand0: round 3", 28, 5)
