@@ -24,7 +24,7 @@ extern "C" {
 
 typedef void* regt_stream_t;
 
-#define REGT_ABI_VERSION 6
+#define REGT_ABI_VERSION 7
 
 int32_t regt_abi_version(void);
 /* Message of the last failing call on this thread ("" if none). */
@@ -179,6 +179,10 @@ typedef struct regt_graph {
      * built for these, and the gradient blocks of the other regions receive just the term every region shares.
      * 0, 0 = all of [0, R). */
     int32_t region_lo, region_hi;
+    /* 1 = node_region is non-decreasing (the nodes of a region are contiguous: what every shipped decomposition produces).  The bf16
+     * arithmetic then runs the row-owning fused forward kernel (csrc/fused_rows.hip); 0 = unknown / not sorted: the 64-row fused
+     * kernel, which handles any order.  (ABI v7) */
+    int32_t region_sorted;
 } regt_graph;
 
 typedef struct regt_params {

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # REGT_LIB_DIR: a developer build of the same library in another directory (build.py honours the same variable), e.g. the
 # workgroup-trace build of tools/wg_trace.py; never a different implementation
 LIB_PATH = os.path.join(os.environ.get("REGT_LIB_DIR") or os.path.join(HERE, "lib"), "libregtgcn_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -50,7 +50,7 @@ class Graph(C.Structure):
     _fields_ = [("rowptr", vp), ("col", vp), ("val", vp), ("node_region", vp), ("chunk_tab", vp),
                 ("chunk_region", vp), ("n_chunks", C.c_int32),
                 ("m_rowptr", vp), ("m_col", vp), ("m_val_a", vp), ("m_val_l", vp), ("overlap", C.c_int32),
-                ("region_lo", C.c_int32), ("region_hi", C.c_int32)]
+                ("region_lo", C.c_int32), ("region_hi", C.c_int32), ("region_sorted", C.c_int32)]
 
 
 _PARAM_FIELDS = [("attention", vp), ("conv_lin_w", vp * 3), ("conv_bias", vp * 3), ("gate_w", vp * 3),

@@ -226,6 +226,13 @@ bool xbf_ok(const regt_dims& d, const regt_graph& g, bool h_ext, int x_rows, boo
            fused_forward_ok(d.C, d.F) && ((long)d.T * d.F) % 64 == 0 && (!packed_fp32 || x_rows <= 2 * d.N) &&
            (long)(x_rows > d.N ? x_rows : d.N) * d.T * d.F * 2 < (1L << 32) - 4096;
 }
+// The row-owning fused forward (fused_rows.hip) instead of the 64-row one: C = 256, F = 32 / 64, T <= 16 and region ids sorted by node.
+// The three-launch path of the same arithmetic follows with its per-node sums (CandArgs::node_sum_rows), whichever forward runs:
+// the forms stay bit-identical (tests/test_gpu_fused.py).  regt_set_option("fused_rows", 0): the 64-row kernel everywhere.
+static int g_opt_fused_rows = 1;
+bool fused_rows_form(const regt_dims& d, const regt_graph& g) {
+    return g_opt_fused_rows && fused_forward_rows_ok(d.C, d.F, d.T) && d.regional && !g.overlap && (d.R == 1 || g.region_sorted);
+}
 struct WbPtrs { const float *U[3], *UT[3], *Gzr, *Gh, *A0, *Aall; long ar_stride; };
 WbPtrs wb_ptrs(const float* Wb, long C, long F, long R) {
     const char* b = reinterpret_cast<const char*>(Wb);
@@ -523,7 +530,8 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
             a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = 1;
             PROF("fused_forward", st);
             TRY(launch_zero_f32(hidden, (long)N * C, st));
-            TRY(launch_fused_forward(a, C, F, st));
+            if (fused_rows_form(d, g)) TRY(launch_fused_forward_rows(a, C, F, st));
+            else TRY(launch_fused_forward(a, C, F, st));
         }
         return head_forward(d, p, hidden, L.y1, pred, st);
     }
@@ -622,6 +630,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         a.num_nodes = N; a.T = T; a.C = C;
         a.bias = L.ch; a.ZR = L.ZR; a.h = H; a.probs = L.probs; a.Ht = L.Ht; a.OH = hidden;
         a.act_bf16 = abf;
+        a.node_sum_rows = abf && fused_rows_form(d, g) ? 16 : 64;
         PROF("gemm_candidate", st);
         TRY(launch_gemm_candidate(a, st));
     }
@@ -1191,6 +1200,7 @@ const char* regt_last_error(void) { return g_err; }
 int32_t regt_set_option(const char* name, int32_t value) {
     REGT_CHECK_ARG(name != nullptr, "regt_set_option: name is NULL");
     if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
+    if (!strcmp(name, "fused_rows")) { const int prev = g_opt_fused_rows; g_opt_fused_rows = value ? 1 : 0; return prev; }
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);

@@ -1705,7 +1705,11 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
         }
         if (k % (NR / 2) == NR / 2 - 1) {
             __syncthreads();
-            const int r_lo = 64 * half, r_hi = (FULL ? 64 * half + 63 : (nvalid - 1 < 64 * half + 63 ? nvalid - 1 : 64 * half + 63));
+            // the half is blended: per block of `node_sum_rows` rows (the whole half, or the 16 rows a wave of the row-owning fused
+            // kernel holds) the rows of every node that meets the block are summed in row order
+            const int brows = a.node_sum_rows == 16 ? 16 : 64;
+            for (int r_lo = 64 * half; r_lo < 64 * half + 64; r_lo += brows) {
+            const int r_end = r_lo + brows - 1, r_hi = FULL ? r_end : (nvalid - 1 < r_end ? nvalid - 1 : r_end);
             if (FULL || r_hi >= r_lo) {
                 const int n_first = rowtab[r_lo].nt >> 8, n_last = rowtab[r_hi].nt >> 8;
                 for (int nd = n_first + rr; nd <= n_last; nd += 16) {
@@ -1715,7 +1719,7 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
                     hi = hi > r_hi ? r_hi : hi;
                     float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
                     for (int r = lo; r <= hi; ++r) {
-                        const float4* p = reinterpret_cast<const float4*>(lds + (r - r_lo) * G_LDS_KROW + c8);
+                        const float4* p = reinterpret_cast<const float4*>(lds + (r - 64 * half) * G_LDS_KROW + c8);
                         const float4 u = p[0], w = p[1];
                         s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
                         s1.x += w.x; s1.y += w.y; s1.z += w.z; s1.w += w.w;
@@ -1731,6 +1735,7 @@ __device__ __forceinline__ void cand8_epilogue(const CandArgs& a, const SplitCor
                         }
                     }
                 }
+            }
             }
         }
     }

@@ -131,6 +131,8 @@ struct CandArgs {
     float* Ht;              // (M, C) out
     float* OH;              // (num_nodes, C) out
     int act_bf16 = 0;       // ZR, h and Ht hold bf16 elements (all three together)
+    int node_sum_rows = 64; // bf16 storage: the rows of a node are summed in row order inside blocks of 64 (the staged half) or 16
+                            //   rows (what a wave of fused_rows.hip owns: the two paths then agree bit for bit); T <= 16 for the latter
 };
 int launch_gemm_candidate(const CandArgs& a, hipStream_t st);
 
@@ -269,6 +271,9 @@ struct FusedFwdArgs {
 long fused_trace_fetch(long* out, long capacity);
 int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st);
 bool fused_forward_ok(int C, int F);
+// the row-owning form (fused_rows.hip): a wave owns 16 whole rows, weights stream through LDS; needs region ids sorted by node
+int launch_fused_forward_rows(const FusedFwdArgs& a, int C, int F, hipStream_t st);
+bool fused_forward_rows_ok(int C, int F, int T);
 
 // ---- fused data gradients of the cell for the bf16 arithmetic (fused.hip): cell_bwd + dgrad_candidate + dgrad_gates in one kernel
 struct FusedBwdArgs {

@@ -112,6 +112,7 @@ def _graph_struct(graph: PreparedGraph, periods: int) -> _lib.Graph:
         g.m_val_a, g.m_val_l = graph.m_val_a.data_ptr(), graph.m_val_l.data_ptr()
     g.overlap = 1 if graph.overlap else 0
     g.region_lo, g.region_hi = graph.region_lo, graph.region_hi
+    g.region_sorted = 1 if graph.region_sorted else 0
     cache[periods] = g
     return g
 

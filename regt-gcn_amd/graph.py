@@ -46,6 +46,14 @@ class PreparedGraph:
     def device(self):
         return self.rowptr.device
 
+    @property
+    def region_sorted(self) -> bool:
+        """Region ids non-decreasing by node (regt_graph.region_sorted): the nodes of a region are contiguous."""
+        if "_region_sorted" not in self.__dict__:
+            nr = self.node_region_host
+            self.__dict__["_region_sorted"] = bool(len(nr) < 2 or np.all(nr[1:] >= nr[:-1]))
+        return self.__dict__["_region_sorted"]
+
     def chunks_for(self, periods: int):
         """(chunk_tab (n,2) int32, chunk_region (n,) int32, n): row ranges of (node*T+t) rows inside one region."""
         if periods not in self._chunks:
