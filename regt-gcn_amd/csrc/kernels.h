@@ -265,6 +265,8 @@ struct FusedFwdArgs {
     long M; int T; float slope; int act_lrelu;
     long nodes;                               // M / T                                            } filled in by launch_fused_forward
     unsigned long long pmask;                 // bit k T for every k T < 64 (rows that start a node) }
+    const char* wbase;                        // fused_rows.hip: the weight blocks as 32-bit offsets from one base (filled in by its launcher)
+    unsigned o_uz, o_ur, o_uh, o_gzr, o_gh, o_a0, o_aall;
     int dbg;                                  // timing-only switches (REGT_FUSED_DBG, fused.hip); 0 in normal operation
     long* trace;                              // developer trace buffer (REGT_FUSED_TRACE) or nullptr
 };

@@ -3,6 +3,7 @@
 Prints, over all 64-row tiles of one launch, the mean / median shader-clock cycles between the stamps."""
 import ctypes, os, sys
 BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+ROWS = len(sys.argv) > 1 and sys.argv[1] == "rows"      # the row-owning forward kernel (fused_rows.hip): 128-row tiles, 17 stamps
 os.environ["REGT_FUSED_TRACE"] = "2" if BWD else "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -25,6 +26,20 @@ for _ in range(3):
             model.forward_prepared(x, graph)
 torch.cuda.synchronize()
 tiles = (n * t + 63) // 64
+if ROWS:
+    tiles = (n * t + 127) // 128
+    buf = (ctypes.c_int64 * (32 * tiles))()
+    got = lib.regt_debug_trace(buf, 32 * tiles)
+    f = np.frombuffer(buf, dtype=np.int64)[:got].reshape(-1, 32)
+    units = ["embed j=0", "embed j=1", "R j=0", "R j=1", "Z j=0", "cand j=0", "Z j=1", "cand j=1"]
+    print(f"{f.shape[0]} tiles of 128 rows; cycles (mean / median / p90):")
+    for u, nm in enumerate(units):
+        k = f[:, 1 + 2 * u] - f[:, 2 * u]
+        e = f[:, 2 + 2 * u] - f[:, 1 + 2 * u]
+        print(f"  {nm:10s} K loop {k.mean():8.0f} {np.median(k):8.0f} {np.percentile(k, 90):8.0f}   epilogue {e.mean():8.0f} {np.median(e):8.0f} {np.percentile(e, 90):8.0f}")
+    tot = f[:, 16] - f[:, 0]
+    print(f"  tile total {tot.mean():9.0f} {np.median(tot):9.0f} {np.percentile(tot, 90):9.0f}")
+    sys.exit(0)
 SLOTS = 32
 buf = (ctypes.c_int64 * (SLOTS * tiles))()
 got = lib.regt_debug_trace(buf, SLOTS * tiles)
