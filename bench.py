@@ -429,8 +429,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh children, BEFORE this process touches the GPU
+        # (nothing above initialises HIP; a process that has must never exec another program on this pool), and hand back their code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1 (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     shard_of_8 = args.workload == "cfg5shard"
@@ -538,8 +549,17 @@ def main():
             pipe.release(i % 2)
         return loss
 
+    ar_events = []
+
     def epoch_end():
-        R.dist.allreduce_gradients(params)
+        if world > 1 or force_shard:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            R.dist.allreduce_gradients(params)
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            R.dist.allreduce_gradients(params)
         opt.step()
         opt.zero_grad(set_to_none=False)
 
@@ -572,7 +592,11 @@ def main():
     if profile:
         lib.regt_profile_enable(1)
     loss = None
+    if pipe is not None:
+        pipe.timed = True
     dt, loss = timed(args.steps)
+    if pipe is not None:
+        pipe.timed = False
     allocs_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - alloc0
     stages = {}
     if profile:
@@ -635,6 +659,20 @@ def main():
                        "final_loss": final_loss,
                        "device_allocs_in_timed_region": allocs_timed},
         }
+        if world > 1 or force_shard:
+            # what a SCALE record can be checked against: the group as the collective library sees it, this rank's halo
+            # rows / bytes per step, pack + exchange on the side stream (off the critical path), the gradient all-reduce
+            esz = 2 if rows_bf16 else 4
+            mg = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "rank0_own_nodes": n_local,
+                  "rank0_halo_rows": int(shard.topo.halo_rows), "rank0_halo_bytes_per_step": int(shard.topo.halo_rows) * T * F * esz,
+                  "grad_allreduce_bytes": int(sum(p.numel() for p in params) * 4)}
+            if pipe is not None:
+                mg["pack_and_exchange_side_stream"] = pipe.exchange_ms()
+            if ar_events:
+                torch.cuda.synchronize()
+                ms = [a.elapsed_time(b) for a, b in ar_events]
+                mg["grad_allreduce_ms"] = {"last": ms[-1], "max": max(ms), "calls": len(ms)}
+            out["multi_gpu"] = mg
         if stages:
             per = {}
             gen = mode == 0 and "cell_bwd" not in stages      # fp32: cell_bwd folded into the candidate data gradient (round 4)

@@ -342,10 +342,13 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     L.rowdot = take(M * (C / 128 > 1 ? C / 128 : 1));
     // one slab region per weight gradient (their reductions are deferred into one launch, ReduceQueue): the sum of
     // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
-    long slab = (long)L.nchunks * (C * C + C) + (long)L.nchunks * (2 * C * C + 2 * C)
-              + (long)L.nchunks_s * (C * F) + (long)L.nchunks_s * (2 * C * F) + (long)L.nchunks_s * (C * F + C)
+    // (chunk counts: the launches pick their own -- wgrad_wide / _skinny / _ring_chunking -- so every region is sized for the larger of
+    // the layout's count and what those can return; the paired bf16 launches write (C + F)-wide slabs)
+    auto nmax = [&](long layout_chunks, int nout, int nin) { const long b = wgrad_chunk_bound(nout, nin, M); return b > layout_chunks ? b : layout_chunks; };
+    long slab = nmax(L.nchunks, C, C + F) * ((long)C * (C + F) + C) + nmax(L.nchunks, 2 * C, C + F) * (2L * C * (C + F) + 2 * C)
+              + nmax(L.nchunks_s, C, F) * (C * F) + nmax(L.nchunks_s, 2 * C, F) * (2 * C * F) + (long)L.nchunks_s * (C * F + C)
               + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64
-              + (long)L.nchunks_s * (2 * C * 2 * F + 2 * C) + 64;        // FMT_TCOLLAPSE: dzr^T [x | L~ x] (one or two launches)
+              + nmax(L.nchunks_s, 2 * C, 2 * F) * (2 * C * 2 * F + 2 * C) + 64;   // FMT_TCOLLAPSE: dzr^T [x | L~ x] (one or two launches)
     const long ar_uniform = (long)L.nchunks_s * C * F, ar_tab = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
     slab += ar_tab > ar_uniform ? ar_tab : ar_uniform;
     slab += (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * (C * F + C);     // fused dA0 | dA_r slabs over the region chunk table

@@ -19,6 +19,8 @@
 // element while T <= 16 (a node then meets at most two blocks); the three-launch path sums the same blocks (`node_sum_rows` of
 // CandArgs), so outputs stay bit-identical to it (tests/test_gpu_fused.py).  Longer periods, C != 256 or region ids that are not
 // sorted by node keep fused_fwd_kernel.
+#include <type_traits>
+
 #include "fused_common.h"
 
 namespace regt {
@@ -26,8 +28,9 @@ namespace regt {
 namespace {
 
 constexpr int FR_ROWS = 128;             // rows of a tile: 8 waves x 16
-constexpr int FR_SLOTS = 8;              // ring slots
-constexpr int FR_AHEAD = 7;              // slices requested ahead of the one being consumed
+constexpr int FR_SLOTS = 16;             // ring slots (128 KB: a request takes ~3 k cycles to land under load, and what is in flight
+                                         //   sets the rate -- with 8 slots the K loops waited for the ring, matrix work or not)
+constexpr int FR_AHEAD = 15;             // slices requested ahead of the one being consumed
 constexpr int FR_SLICE_B = 8192;         // 32 k x 128 columns of bf16 in MFMA fragment order (eight 1 KB blocks of launch_cvt_bf16_frag)
 constexpr int FR_IMG_B = 2048;           // a wave's epilogue image: 16 rows x 32 columns fp32
 constexpr int FR_C = 256;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     using L = FusedRowsLds;
     extern __shared__ __attribute__((aligned(16))) char flds[];
     float* biasl = reinterpret_cast<float*>(flds + L::BIAS_OFF);
-    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4, lr = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int v = __builtin_amdgcn_readfirstlane(tid >> 6);       // the wave: rows 16 v .. 16 v + 15 of the tile
     const unsigned uT = (unsigned)a.T;
     const long tiles = (a.M + FR_ROWS - 1) / FR_ROWS;
@@ -127,13 +130,15 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     // blocks (32 columns x 16 k each, lane' = 32 (k-group % 2) + column % 32): block 2 (cb / 2) + g / 2, lane' 32 (g % 2) + 16 (cb % 2) + c
     const int bf_lane = 1024 * (g >> 1) + 512 * (g & 1) + 16 * r;
     int rg_cur = 0, rg_nxt = 0;                                  // first region of the tile at hand / of the workgroup's next tile
-    bool has_next = false;
+    bool has_next = false, first_tile = true;
     // acc[cb] += A (16 rows x 32 k, this wave's) x slice[cb]^T for the 8 column blocks of slice s of the tile.  The B fragments are
-    // read one HALF slice ahead of the MFMAs that use them (bA: column blocks 0..3 of the slice at hand, read during the previous
-    // step; bB: blocks 4..7, read at the start of this one), so an LDS round trip always has four MFMAs of this wave in front of it:
-    //     read bB(s) | MFMA bA(s) | slice s + 1 landed: wait + barrier | request slice s + 7 | read bA(s + 1) | MFMA bB(s)
-    // The barrier in the middle says (a) every wave's piece of slice s + 1 has landed and (b) every wave has finished step s - 1,
-    // i.e. all reads of slice s - 1 -- whose slot the new request overwrites.
+    // read TWO half slices (eight MFMAs of this wave) ahead of the MFMAs that use them, through three half-slice buffers: half h of a
+    // tile (h = 2 s + 0 / 1: column blocks 0..3 / 4..7 of slice s) lives in buffer h % 3 -- static at every call site --
+    //     even s: slices s + 1, s + 2 landed: wait + barrier | two requests | read half 2 s + 2 | MFMA half 2 s | read half 2 s + 3 | MFMA half 2 s + 1
+    // (all eight waves read at once after a barrier: with only four MFMAs in front of a read its latency was in the open -- 500
+    // cycles per slice for 256 of matrix work).  The barrier says (a) every wave's piece of slice s + 1 has landed and (b) every wave
+    // has issued the MFMAs of step s - 1, i.e. has read slice s - 1 -- whose slot the new request overwrites.  A tile's first step
+    // reads its own two halves as well (the mapping restarts with every tile).
     // vector-memory operations (other than ring requests) issued right after slice t of a tile: the 16-byte stores of the epilogue
     // that follows it (the per-node sums' stores / atomics come on top: not counted, the wait is then a little stricter than needed),
     // after the last slice also the next tile's row loads
@@ -146,51 +151,92 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         if (t == g0 + 6 * gl - 1) return 4 + 3 * KF + 1;                                      // ... and the next tile's rows
         return 0;
     };
-    // ... issued between the request for slice s + 1 (in the middle of step s - 6) and the middle of step s
+    // ... issued between the request for slice s + 1 (at step s + 1 - FR_AHEAD) and step s
     auto vm_after = [&](int s) {
         int n = 0;
 #pragma unroll
-        for (int t = s - 6; t < s; ++t) n += vm_epi(t < 0 ? t + S_TILE : t);
+        for (int t = s - (FR_AHEAD - 1); t < s; ++t) n += vm_epi(t < 0 ? t + S_TILE : t);
         return n;
     };
     auto wait_landed = [&](int n) {                              // (n is a constant at every call site: the switch folds)
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 256)    // timing-only developer builds: no wait and no barrier / (128) barrier only
+        return;
+#elif defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 128)
+        asm volatile("s_barrier" ::: "memory");
+        return;
+#endif
         switch (n) {
 #define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")\n\ts_barrier" ::: "memory"); break;
-            W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28)
+            W_(11) W_(12) W_(13) W_(14) W_(15) W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31) W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45)
 #undef W_
-            default: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory"); break;
         }
     };
-    bf16x8 bA[4];
-    auto read_half = [&](bf16x8 (&b)[4], unsigned slot, int hf) {
+    bf16x8 bq0[4], bq1[4], bq2[4];                               // (three named arrays, chosen by if-chains that fold at every call site: a
+                                                                 // [3][4] array indexed with h % 3 ends up in scratch memory)
+    auto read_half = [&](int k, unsigned slot, int hf) {
         const char* sl = flds + L::RING_OFF + slot * FR_SLICE_B + bf_lane + 4096 * hf;
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = *reinterpret_cast<const bf16x8*>(sl + 2048 * (cb >> 1) + 256 * (cb & 1));
+        for (int cb = 0; cb < 4; ++cb) {
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 64)     // timing-only developer build: no B fragment reads
+            bf16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+            asm volatile("" : "+v"(x) : "v"(sl));
+#else
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(sl + 2048 * (cb >> 1) + 256 * (cb & 1));
+#endif
+            if (k == 0) bq0[cb] = x; else if (k == 1) bq1[cb] = x; else bq2[cb] = x;
+        }
+    };
+    auto mfma_half = [&](int k, f32x4 (&acc)[8], int hf, const bf16x8& af) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const bf16x8 x = k == 0 ? bq0[cb] : (k == 1 ? bq1[cb] : bq2[cb]);
+#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 1)      // timing-only developer build: no matrix instructions (operands kept alive)
+            asm volatile("" :: "v"(x), "v"(af));
+#else
+            if (hf == 0) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x, acc[cb], 0, 0, 0);
+            else acc[4 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x, acc[4 + cb], 0, 0, 0);
+#endif
+        }
     };
     auto consume = [&](int s, f32x4 (&acc)[8], const bf16x8& af) {
-        bf16x8 bB[4];
-        read_half(bB, c_slot, 1);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bA[cb], acc[cb], 0, 0, 0);
-        // This wave's own request for slice s + 1 is done when all of its vector-memory operations are, except the ones issued after
-        // it (they retire in issue order): the requests s + 2 .. s + 6 and whatever the epilogues in between stored -- vm_after(s),
-        // counted from the static schedule.  Counting too few is safe (a stricter wait); counting exactly matters: waiting for an
-        // epilogue's last stores (or the next tile's row loads) to be acknowledged cost every K loop its first ~2 k cycles.
-        if (s + FR_AHEAD < S_TILE) {
-            wait_landed(5 + vm_after(s));
-            request(s + FR_AHEAD, rg_cur);
-        } else if (has_next) {
-            wait_landed(5 + vm_after(s));
-            request(s + FR_AHEAD - S_TILE, rg_nxt);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // (the workgroup's last tile: fewer requests are outstanding)
+        // One barrier per TWO slices (even s; 16 MFMAs per wave in between -- with one per slice the K loops ran at ~500 cycles per
+        // slice for 256 of matrix work): slices s + 1 and s + 2 have landed -- this wave's own requests for them are done when all of
+        // its vector-memory operations are, except the ones issued after them (they retire in issue order): the requests s + 3 ..
+        // s + FR_AHEAD - 2 and whatever the epilogues in between stored (vm_after(s), counted from the static schedule; counting too few is
+        // safe -- a stricter wait -- but waiting for an epilogue's last stores to be acknowledged costs the K loop its first steps).
+        // The barrier also says that every wave has issued the MFMAs of steps s - 2 and s - 1, i.e. has read slices s - 2 and
+        // s - 1: their slots take the two new requests.
+        if ((s & 1) == 0) {
+            if (s + FR_AHEAD < S_TILE) {
+                // (the workgroup's first tile has no epilogue behind it: counting one would make the wait too weak)
+                if (first_tile && vm_after(s) > 0 && s < FR_AHEAD) wait_landed(FR_AHEAD - 4);
+                else wait_landed(FR_AHEAD - 4 + vm_after(s));
+            } else if (has_next) {
+                wait_landed(FR_AHEAD - 4 + vm_after(s));
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's last tile: fewer requests are outstanding)
+            }
         }
-        c_slot = (c_slot + 1) & (FR_SLOTS - 1);
-        read_half(bA, c_slot, 0);                                // (past the workgroup's last slice: stale bytes, never used)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[4 + cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bB[cb], acc[4 + cb], 0, 0, 0);
+        // The two requests that the barrier of the even step makes room for are issued at two points of that step (waves 0-3 before
+        // its first four MFMAs, waves 4-7 before the second four; always inside the even step: the vm_after() counts assume that the
+        // requests precede the epilogue that may follow it).  All eight waves asking right behind the barrier queued up at the
+        // texture unit -- the last wave started its MFMAs ~300 cycles late, and the next barrier waits for the last wave.
+        auto issue_pair = [&](int se) {                          // se: the even step
+            if (se + FR_AHEAD < S_TILE) { request(se + FR_AHEAD - 1, rg_cur); request(se + FR_AHEAD, rg_cur); }
+            else if (has_next) { request(se + FR_AHEAD - 1 - S_TILE, rg_nxt); request(se + FR_AHEAD - S_TILE, rg_nxt); }
+        };
+        if ((s & 1) == 0 && v < 4) issue_pair(s);
+        const unsigned nslot = (c_slot + 1) & (FR_SLOTS - 1);
+        if (s == 0) { read_half(0, c_slot, 0); read_half(1, c_slot, 1); }
+        if (s + 1 < S_TILE) read_half((2 * s + 2) % 3, nslot, 0);
+        mfma_half((2 * s) % 3, acc, 0, af);
+        if ((s & 1) == 0 && v >= 4) issue_pair(s);
+        if (s + 1 < S_TILE) read_half((2 * s + 3) % 3, nslot, 1);
+        mfma_half((2 * s + 1) % 3, acc, 1, af);
+        c_slot = nslot;
     };
-    static_assert(FR_AHEAD == 7 && FR_SLOTS == 8, "the hand-written vmcnt counts and the slot arithmetic assume seven requests ahead in eight slots");
+    static_assert(FR_AHEAD == 15 && FR_SLOTS == 16 && S_TILE % 2 == 0 && S_TILE > FR_AHEAD, "the hand-written vmcnt(11) and the slot arithmetic assume fifteen requests ahead in sixteen slots, slices in pairs");
 
     // ---- epilogue geometry: accumulator pieces of 16 rows x 32 columns through the wave's image ------------------------------------
     // accumulator lane (c = l & 15, g): rows 4 g + i (i = register), column c of its 16-column block; epilogue lane (r = l & 15, g):
@@ -265,9 +311,10 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     FrTileInfo info = tile_info(tile);
     request_rows(tile);
 #pragma unroll
-    for (int s = 0; s < FR_AHEAD; ++s) request(s, info.rg_first);
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");              // slice 0 has landed (everything older than the 6 youngest requests is done)
-    read_half(bA, 0, 0);
+    for (int s = 0; s < FR_AHEAD - 1; ++s) request(s, info.rg_first);
+    // (the first tile's first wait counts operations that a steady-state tile has behind its requests -- here they are in front:
+    // make sure slices 0, 1 and 2 have landed before the loop)
+    asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
 
 #pragma unroll 1
     for (; tile < tiles; tile += gridDim.x) {
@@ -301,8 +348,9 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         for (int kb = 0; kb < KF; ++kb) axA[kb] = axf[kb];
 
         // ---- regional embedding h = act(x A0^T + (L~ x) A_region^T + b'): the output IS the A operand of both gates ------------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        // (a generic lambda over a constant j, not a loop: the bodies are too long for hipcc to unroll, and every index must be static)
+        auto unit_embed = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             f32x4 acc[8];
             zero8(acc);
             const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,10 +393,13 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
                 hA[4 * j + q] = __builtin_bit_cast(bf16x8, pk);
             }
             FT_MARK(2 + 2 * j);
-        }
+        };
+        unit_embed(std::integral_constant<int, 0>{});
+        unit_embed(std::integral_constant<int, 1>{});
         // ---- reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R: the candidate's A operand --------------------------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        // (a generic lambda over a constant j, not a loop: the bodies are too long for hipcc to unroll, and every index must be static)
+        auto unit_r = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             f32x4 acc[8];
             zero8(acc);
 #pragma unroll
@@ -374,10 +425,13 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
                 qA[4 * j + q] = __builtin_bit_cast(bf16x8, pq);
             }
             FT_MARK(6 + 2 * j);
-        }
+        };
+        unit_r(std::integral_constant<int, 0>{});
+        unit_r(std::integral_constant<int, 1>{});
         // ---- per 128 columns: update gate Z (kept packed), candidate H~, blend, per-node sums ----------------------------------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        // (a generic lambda over a constant j, not a loop: the bodies are too long for hipcc to unroll, and every index must be static)
+        auto unit_zc = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
             u32x4_t zk[4];
             {
                 f32x4 acc[8];
@@ -416,7 +470,10 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
                 stage(eg, acc[2 * q], acc[2 * q + 1]);
                 const V8 vv = img8(eg);
                 const V8 b = bias8(3 * C + 128 * j + 32 * q + 8 * g);
-                const V8 hv = f_widen8(__builtin_bit_cast(u32x4_t, hA[4 * j + q]));
+                // (opaque: left alone, hipcc keeps the WIDENED h of the reset-gate epilogue alive until here -- 8 registers per round, spilled)
+                u32x4_t hraw = __builtin_bit_cast(u32x4_t, hA[4 * j + q]);
+                asm volatile("" : "+v"(hraw));
+                const V8 hv = f_widen8(hraw);
                 const V8 Zv = f_widen8(zk[q]);
                 const V8 ht = f_tanh8(vv, b);
                 V8 bl;
@@ -428,29 +485,35 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
                 // Per-node sums over the wave's 16 rows, in row order (see fused.hip: one running sum per lane = column lr of the
                 // piece; lanes 32..63 duplicate and store nothing; a start row multiplies the carried sum by 0, an end row hands it
                 // over -- a plain store when all of the node's rows lie in this block, else an atomic add).
-                float cv[16];
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) cv[rr] = imgw[rr * 32 + (eg.lr ^ (4 * fr_par(rr)))];
                 unsigned sm = smask, em = emask, am = amask;
                 asm volatile("" : "+s"(sm), "+s"(em), "+s"(am));
                 const int ohv = eg.lane < 32 ? (32 * q + eg.lr) * 4 : 0x7ffffff0;
                 float csum = 0.f;
                 int ohs = 0;
 #pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    float keep;
-                    asm volatile("s_bitcmp1_b32 %1, %2\n\ts_cselect_b32 %0, 0, 1.0" : "=s"(keep) : "s"(sm), "n"(rr) : "scc");
-                    csum = fmaf(csum, keep, cv[rr]);
-                    if ((em >> rr) & 1u) {
-                        const bool part = (am >> rr) & 1u;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(csum), sOH, ohv, part ? 0x7ffffff0 : ohs, 0);
-                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(csum, sOH, ohv, part ? ohs : 0x7ffffff0, 0);
-                        ohs += C * 4;
+                for (int r8 = 0; r8 < 16; r8 += 8) {             // (eight rows at a time: the LDS reads first, then the serial chain)
+                    float cv[8];
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) cv[rr] = imgw[(r8 + rr) * 32 + (eg.lr ^ (4 * fr_par(r8 + rr)))];
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        float keep;
+                        asm volatile("s_bitcmp1_b32 %1, %2\n\ts_cselect_b32 %0, 0, 1.0" : "=s"(keep) : "s"(sm), "n"(r8 + rr) : "scc");
+                        csum = fmaf(csum, keep, cv[rr]);
+                        if ((em >> (r8 + rr)) & 1u) {
+                            const bool part = (am >> (r8 + rr)) & 1u;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(csum), sOH, ohv, part ? 0x7ffffff0 : ohs, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(csum, sOH, ohv, part ? ohs : 0x7ffffff0, 0);
+                            ohs += C * 4;
+                        }
                     }
                 }
             }
             FT_MARK(12 + 4 * j);
-        }
+        };
+        unit_zc(std::integral_constant<int, 0>{});
+        unit_zc(std::integral_constant<int, 1>{});
+        first_tile = false;
     }
     // (the ring holds no request any more: the producer stopped with the last tile's last slice, which has been consumed)
 #undef FT_MARK

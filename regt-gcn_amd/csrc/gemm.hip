@@ -1254,6 +1254,32 @@ bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
     *nchunks = (int)((M + kc - 1) / kc);
     return true;
 }
+// Upper bound of the row chunks ANY of the three per-launch chunkers above can return for a (Nout x Nin) gradient over M rows, whatever
+// the arithmetic / switches at launch time: make_layout sizes the slab regions with it (the layout's own ~128 / ~512 chunks were too few
+// once the launches started to pick their counts: C = 128 in fp32 asks for 768 chunks of dUh).
+long wgrad_chunk_bound(int Nout, int Nin, long M) {
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    int skinny = 2, wave32 = 1;
+    if (const char* e = getenv("REGT_WGRAD_SKINNY")) skinny = atoi(e) > skinny ? atoi(e) : skinny;
+    if (const char* e = getenv("REGT_WGRAD_WAVE32")) wave32 = atoi(e) > wave32 ? atoi(e) : wave32;
+    const long cand[3] = {(long)cus * 3 * wave32 / ((long)cdiv(Nout, 128) * cdiv(Nin, 128)),      // wide fp32 / bf16x3, ring (128-row tiles)
+                          (long)cus * skinny / cdiv(Nout, 128),                                   // skinny
+                          (long)cus * 3 / ((long)cdiv(Nout, 256) > 0 ? (long)cdiv(Nout, 256) * cdiv(Nin, 128) : 1)};
+    long best = 0;
+    for (long nch : cand) {
+        if (nch < 1) continue;
+        long kc = ((M + nch - 1) / nch + 31) / 32 * 32;
+        if (kc > 32768) {
+            const long waves = (kc + 32767) / 32768;
+            kc = ((M + nch * waves - 1) / (nch * waves) + 31) / 32 * 32;
+        }
+        if (kc < 32) kc = 32;
+        const long n = (M + kc - 1) / kc;
+        best = n > best ? n : best;
+    }
+    return best;
+}
 int wgrad_ring_option(int value) {
     const int prev = wgrad_ring_depth();
     g_wgrad_ring = value < 0 ? 0 : value;

@@ -112,6 +112,7 @@ int wgrad_wave_option(int value);    // one-wave row chunking of ring-kernel lau
 bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);
 bool wgrad_skinny_chunking(int Nout, long M, int* kchunk, int* nchunks);            // skinny (Nin <= 32) fp32-MFMA kernel
 bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks);   // wide fp32 / bf16x3 kernels (experiment)
+long wgrad_chunk_bound(int Nout, int Nin, long M);   // upper bound of what the three can return (slab sizing, api.hip make_layout)
 bool wgrad_ring_active();             // the ring kernel takes the bf16-stored weight gradients (pairs pay off with it)
 int wgrad_ring_option(int value);    // runtime A/B switch (regt_set_option "wgrad_ring"): ring depth of the bf16 weight gradient
 int dgrad1_gen_option(int value);    // runtime A/B switch (regt_set_option "dgrad1_gen")

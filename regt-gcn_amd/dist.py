@@ -188,15 +188,33 @@ class HaloPipeline:
         self.free = [torch.cuda.Event() for _ in range(2)]
         for e in self.free:
             e.record(torch.cuda.current_stream(device))
+        # optional timing of pack + exchange on the side stream (bench.py's N > 1 line): event pairs of the last submits
+        self.timed = False
+        self._spans = []
 
     def submit(self, slot: int, x: torch.Tensor):
         topo = self.shard.topo
         self.stream.wait_event(self.free[slot])
         self.stream.wait_stream(torch.cuda.current_stream(x.device))      # x may have been produced just now
         with torch.cuda.stream(self.stream):
+            if self.timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
             self._pack(x, self.buf[slot])
             exchange_boundary_rows(self.buf[slot].view(topo.x_rows, self.T * self.F), topo, self.shard.send_idx, self.group)
+            if self.timed:
+                e1.record(self.stream)
+                self._spans.append((e0, e1))
+                del self._spans[:-64]
             self.ready[slot].record(self.stream)
+
+    def exchange_ms(self):
+        """Mean / max device time of pack + halo exchange over the timed submits (side stream: off the critical path); synchronises."""
+        if not self._spans:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._spans]
+        return {"mean_ms": sum(ms) / len(ms), "max_ms": max(ms), "samples": len(ms)}
 
     def acquire(self, slot: int) -> torch.Tensor:
         torch.cuda.current_stream(self.buf[slot].device).wait_event(self.ready[slot])

@@ -831,3 +831,32 @@ def test_big_tile_shapes_take_the_round4_kernels():
     ms = R.RegionalTemporalGCN(node_features=8, num_nodes=ns, periods=12, output_dim=1, num_regions=5).cuda()
     gs = ms.prepare_graph(eis.cuda(), [i.cuda() for i in ris], [a.cuda() for a in rws])
     assert "cell_bwd" in stages(ms, gs, xs.cuda(), ys)
+
+
+@pytest.mark.parametrize("arith_mode", [0, 2])
+def test_weight_gradient_slabs_fit_at_hidden_128_and_many_rows(arith_mode):
+    """The backward picks its row-chunk counts per launch (768 chunks of dUh at C = 128 in fp32); the slab regions of the workspace
+    are sized for them (wgrad_chunk_bound): ~400 k rows at hidden 128, F = 8 used to fail with 'weight-gradient slab ... exceeds the
+    workspace region'.  Also two runs agree bit for bit (deterministic partial-slab reduction at these chunk counts)."""
+    import regtgcn_amd as R
+    lib = R.load_library()
+    n, e, regions, f, t, o, hidden = 34000, 200000, 4, 8, 12, 1, 128
+    ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=11)
+    y = torch.rand(n, o, generator=torch.Generator().manual_seed(5)).cuda()
+    prev = lib.regt_set_gemm_mode(arith_mode)
+    try:
+        torch.manual_seed(0)
+        mod = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions, hidden_channels=hidden).cuda()
+        g = mod.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        runs = []
+        for _ in range(2):
+            mod.zero_grad(set_to_none=True)
+            pred, _h = mod.forward_prepared(x.cuda(), g)
+            torch.mean((pred - y) ** 2).backward()
+            runs.append({k: q.grad.detach().clone() for k, q in mod.named_parameters() if q.grad is not None})
+        torch.cuda.synchronize()
+    finally:
+        lib.regt_set_gemm_mode(prev)
+    for k in runs[0]:
+        assert bool(torch.isfinite(runs[0][k]).all()), k
+        assert torch.equal(runs[0][k], runs[1][k]), k

@@ -95,3 +95,33 @@ def test_bench_shard_path_with_one_rank():
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
+    assert out["multi_gpu"]["world_size"] == 1 and out["multi_gpu"]["backend"] == "nccl" and out["multi_gpu"]["rank0_halo_rows"] == 0
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_on_one_gpu(launcher):
+    """The driver's N > 1 command (python -m torch.distributed.run ... bench.py --gpus 2) and the plain `python bench.py --gpus 2`
+    (bench.py then starts the ranks itself, before it touches the GPU), with two ranks sharing this box's one GPU
+    (REGT_BENCH_BACKEND=gloo: collectives staged through the host): exit code 0, ONE JSON line from rank 0, the N > 1 block."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["bench.py", "--gpus", "2", "--workload", "small", "--steps", "3", "--warmup", "1"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    else:
+        cmd = [sys.executable] + args
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["REGT_BENCH_BACKEND"] = "gloo"
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong" and np.isfinite(out["config"]["final_loss"])
+    mg = out["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["backend"] == "gloo" and mg["rank0_halo_rows"] > 0
+    assert mg["rank0_halo_bytes_per_step"] == mg["rank0_halo_rows"] * 12 * 32 * 4
+    assert mg["pack_and_exchange_side_stream"]["samples"] >= 3 and mg["grad_allreduce_ms"]["calls"] >= 1

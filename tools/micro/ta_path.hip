@@ -6,6 +6,7 @@
 //   load  rows64     : 16 rows x 64 B (4 lanes per row, 512 B row stride) -- an activation tile read
 //   store contiguous / rows64 / rows32 / rows128 : the same shapes as stores (rows32: 32 rows x 32 B; rows128: 8 rows x 128 B)
 //   mixed            : 5 contiguous loads per rows64 store (the kernel's ratio)
+//   LDS-DMA          : the contiguous load as `global_load_lds_dwordx4` into an LDS ring (what fused_rows.hip streams its weights with)
 // Prints bytes per clock and CU and the cycles one wave instruction occupies the CU's path (at the measured shader clock).
 // Build + run: hipcc --offload-arch=gfx950 -O3 -o ta_path ta_path.hip && ./ta_path
 #include <hip/hip_runtime.h>
@@ -50,6 +51,20 @@ __global__ __launch_bounds__(256, 2) void probe(const char* table, int table_byt
 #pragma unroll
             for (int u = 0; u < U; ++u) acc ^= v[u];
             toff = (toff + U * 1024) % table_bytes;
+        } else if (MODE == 3) {
+            // LDS-DMA (global_load_lds_dwordx4, 1 KB per wave instruction, lane-linear destination): U requests in flight per wave,
+            // into a per-wave ring of U slots of this workgroup's LDS; the oldest is waited for before its slot is reused
+            extern __shared__ char ring[];
+            const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)ring + (wave * U) * 1024);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)((toff + u * 1024) % table_bytes));
+                const char* src = table + so;
+                const unsigned m0v = base + u * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(lane * 16), "s"(src) : "memory");
+            }
+            toff = (toff + U * 1024) % table_bytes;
+            if (U >= 8) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else if (MODE == 1) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -81,9 +96,9 @@ static void run(const char* name, const char* table, int table_bytes, char* out,
     const int grid = 2 * cus, iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<MODE, SHAPE, U><<<grid, 256>>>(table, table_bytes, out, 200, clocks, sink);
+    probe<MODE, SHAPE, U><<<grid, 256, MODE == 3 ? 4 * U * 1024 : 0>>>(table, table_bytes, out, 200, clocks, sink);
     hipEventRecord(e0);
-    probe<MODE, SHAPE, U><<<grid, 256>>>(table, table_bytes, out, iters, clocks, sink);
+    probe<MODE, SHAPE, U><<<grid, 256, MODE == 3 ? 4 * U * 1024 : 0>>>(table, table_bytes, out, iters, clocks, sink);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
@@ -91,7 +106,7 @@ static void run(const char* name, const char* table, int table_bytes, char* out,
     hipMemcpy(h, clocks, grid * sizeof(long long), hipMemcpyDeviceToHost);
     double cyc = 0; for (int i = 0; i < grid; ++i) cyc += (double)h[i];
     cyc /= grid;                                                   // shader cycles of the timed loop (mean over workgroups)
-    const double per_iter = MODE == 2 ? 6.0 : (MODE == 0 ? (double)U : 8.0);                 // wave instructions per iteration
+    const double per_iter = MODE == 2 ? 6.0 : (MODE == 0 || MODE == 3 ? (double)U : 8.0);                 // wave instructions per iteration
     const double insts_cu = 8.0 * iters * per_iter;                // 8 waves per CU
     const double ghz = cyc / (ms * 1e6);
     printf("%-28s %8.3f ms  clock %.2f GHz  %6.1f B/clk/CU  %6.1f cycles per wave instruction (CU path)  chip %.2f TB/s\n", name, ms, ghz,
@@ -113,6 +128,9 @@ int main() {
     run<0, 0, 8>("load  contiguous, 8 in flight", table, table_bytes, out, clocks, sink, cus);
     run<0, 0, 16>("load  contiguous, 16 in flight", table, table_bytes, out, clocks, sink, cus);
     run<0, 0, 32>("load  contiguous, 32 in flight", table, table_bytes, out, clocks, sink, cus);
+    run<3, 0, 4>("LDS-DMA contiguous, 4 in flight", table, table_bytes, out, clocks, sink, cus);
+    run<3, 0, 8>("LDS-DMA contiguous, 8 in flight", table, table_bytes, out, clocks, sink, cus);
+    run<3, 0, 16>("LDS-DMA contiguous, 16 in flight", table, table_bytes, out, clocks, sink, cus);
     run<0, 1>("load  16 rows x 64 B", table, table_bytes, out, clocks, sink, cus);
     run<1, 0>("store contiguous (1 KB)", table, table_bytes, out, clocks, sink, cus);
     run<1, 3>("store 8 rows x 128 B", table, table_bytes, out, clocks, sink, cus);
