@@ -276,6 +276,7 @@ struct Layout {
     float *dA0, *dAall, *dbprime, *dGzr, *dGh, *dczr, *dch;
     int kchunk, nchunks, kchunk_s, nchunks_s, kchunk_head, nchunks_head, cb_npb, cb_blocks;
     long slab_floats;
+    unsigned* tile_ctr;
     size_t bytes;
 };
 
@@ -340,6 +341,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     // per-row <dOH, H'>: one float per row (fused backward kernel, fused.hip) or one partial dot per 128-column tile of the row
     // (fp32 candidate data gradient with a generated left operand, gemm_dgrad1_gen_kernel)
     L.rowdot = take(M * (C / 128 > 1 ? C / 128 : 1));
+    L.tile_ctr = reinterpret_cast<unsigned*>(take(16));      // tile counter of the persistent fused kernels (fused.hip, fused_rows.hip)
     // one slab region per weight gradient (their reductions are deferred into one launch, ReduceQueue): the sum of
     // Uh, Uzr (wide), Gh, Gzr, A0, A_r (skinny), head1, head2 -- 64 floats of slack each for alignment
     // (chunk counts: the launches pick their own -- wgrad_wide / _skinny / _ring_chunking -- so every region is sized for the larger of
@@ -530,7 +532,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
             a.bprime = L.bprime; a.czr = L.czr; a.ch = L.ch; a.probs = L.probs;
             a.node_region = R > 1 ? g.node_region : nullptr;
             a.h = L.h; a.ZR = L.ZR; a.q = L.q; a.Ht = L.Ht; a.OH = hidden;
-            a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = 1;
+            a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = 1; a.tile_ctr = L.tile_ctr;
             PROF("fused_forward", st);
             TRY(launch_zero_f32(hidden, (long)N * C, st));
             if (fused_rows_form(d, g)) TRY(launch_fused_forward_rows(a, C, F, st));
@@ -864,7 +866,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
         a.ZR = L.ZR; a.h = H; a.Ht = L.Ht; a.dOH = L.dOH; a.probs = L.probs;
         a.UhTf = wb.UT[0]; a.UzTf = wb.UT[1]; a.UrTf = wb.UT[2];
         a.dhp = L.dhp; a.dzr = L.dzr; a.dh = DH; a.rowdot = L.rowdot;
-        a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = d.regional ? 1 : 0;
+        a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = d.regional ? 1 : 0; a.tile_ctr = L.tile_ctr;
         {
             PROF("fused_backward", st);
             TRY(launch_fused_backward(a, C, st));

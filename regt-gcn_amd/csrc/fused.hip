@@ -50,7 +50,8 @@ struct FusedFwdLds {
     static constexpr int OPER_B = (C / 16) * PLANE_B;            // h (or q) of the tile as an A operand
     static constexpr int IMG_OFF = 2 * OPER_B;                   // four wave-private 16-row fp32 images
     static constexpr int BIAS_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;   // b' (C), [cz | cr] (2C), ch (C): fp32, copied once per workgroup
-    static constexpr int BYTES = BIAS_OFF + 4 * C * 4;
+    static constexpr int NEXT_OFF = BIAS_OFF + 4 * C * 4;        // the workgroup's next tile (drawn from the tile counter by thread 0)
+    static constexpr int BYTES = NEXT_OFF + 16;
 };
 
 // Persistent: a workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the grid is two workgroups per CU) and requests
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     __syncthreads();                                            // the biases are in LDS
 
 #pragma unroll 1
-    for (; tile < tiles; tile += gridDim.x) {
+    while (tile < tiles) {
+    // (the next tile is drawn from a counter in the workspace: see fused_bwd_kernel)
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF) = a.tile_ctr ? atomicAdd(a.tile_ctr, 1u) + gridDim.x : (unsigned)(tile + gridDim.x);
     // (opaque per tile: hoisted out of the tile loop, the ~30 global / plane offsets derived from them stay live through every K loop)
     asm volatile("" : "+v"(er), "+v"(ec));
     const long m0 = tile * FT_ROWS;
@@ -176,9 +179,6 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     const unsigned mrow0 = (unsigned)m0;
     const unsigned node0 = mrow0 / uT;
     const int t0 = (int)(mrow0 - node0 * uT);                    // period of the tile's first row (wave-uniform)
-    // the tile after this one (clamped: the last round requests the last tile once more instead of branching around the loads)
-    const long tnext = tile + gridDim.x < tiles ? tile + gridDim.x : tiles - 1;
-    const int rg_next = first_region(tnext);
     // Node boundaries of the tile as row masks (bit r = row r; all scalar): a.pmask has the bits k T < 64 (the host's division), so
     // the rows that START a node are pmask shifted to the first such row; a row ENDS a node (inside this tile) when the next one
     // starts one or it is the tile's last row; the ends whose sum is only a part of the node's go to memory as atomic adds: the
@@ -362,6 +362,10 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
     }
     FT_MARK(2);
     __syncthreads();                                            // h planes complete
+    // the tile after this one (clamped: the last round requests the last tile once more instead of branching around the loads)
+    const long tdrawn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF));
+    const long tnext = tdrawn < tiles ? tdrawn : tiles - 1;
+    const int rg_next = first_region(tnext);
     FT_FINE(12);
 
     // ---- phase 1: reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R -> global + q planes ---------------------------
@@ -475,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void fused_fwd_kernel(FusedFwdArgs a) {
         }
         FT_MARK(5 + 2 * j);
     }
+    tile = tdrawn;
     }
 #undef FT_MARK
 #undef FT_FINE
@@ -525,7 +530,8 @@ struct FusedBwdLds {
     static constexpr int OPER_B = (C / 16) * PLANE_B;
     static constexpr int IMG_OFF = 2 * OPER_B;
     static constexpr int DOT_OFF = IMG_OFF + 4 * FT_IMG_ROWS * FT_IMG_LD * 4;
-    static constexpr int BYTES = DOT_OFF + 4 * FT_ROWS * 4;
+    static constexpr int NEXT_OFF = DOT_OFF + 4 * FT_ROWS * 4;   // the workgroup's next tile (drawn from the tile counter by thread 0)
+    static constexpr int BYTES = NEXT_OFF + 16;
 };
 
 template <int C>
@@ -538,12 +544,65 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     char* Rp = flds + L::OPER_B;             // drp
     const int tid = threadIdx.x, lane = tid & 63, lr = lane & 31, lh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long m0 = (long)blockIdx.x * FT_ROWS;
-    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
-    const unsigned mrow0 = (unsigned)m0, uT = (unsigned)a.T;
-    const unsigned node0 = mrow0 / uT;
+    const unsigned uT = (unsigned)a.T;
     const long nodes = a.M / a.T;
-#define FB_MARK(i) do { if (a.trace && tid == 0) a.trace[(long)FT_TRACE_SLOTS * blockIdx.x + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+    const long tiles = (a.M + FT_ROWS - 1) / FT_ROWS;
+#define FB_MARK(i) do { if (a.trace && tid == 0) a.trace[(long)FT_TRACE_SLOTS * tile + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
+    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
+    float* dotw = reinterpret_cast<float*>(flds + L::DOT_OFF);
+    const int er00 = lane >> 2, ec00 = 32 * w + 8 * (lane & 3); // the lane's epilogue row of a round / first of its 8 columns of a tile
+    int er = er00, ec = ec00;
+    // image addresses (floats; swizzle: ft_par, fused_fwd_kernel)
+    const int st_even = 4 * lh * FT_IMG_LD + (lr ^ (4 * lh)), st_odd = 4 * lh * FT_IMG_LD + (lr ^ (4 * (lh ^ 1)));
+    const int e_lo = er00 * FT_IMG_LD + 4 * ((2 * (lane & 3)) ^ ft_par(er00)), e_hi = er00 * FT_IMG_LD + 4 * ((2 * (lane & 3) + 1) ^ ft_par(er00));
+    auto stage = [&](const f32x16 (&acc)[2], int rnd) {
+        const int mi = rnd >> 1, rd = rnd & 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
+            imgw[((q & 3) + 8 * (q >> 2)) * FT_IMG_LD + ((q & 1) ? st_odd : st_even)] = mi ? acc[1][reg] : acc[0][reg];
+        }
+    };
+    auto img8 = [&]() {
+        const float4 lo = *reinterpret_cast<const float4*>(imgw + e_lo), hi = *reinterpret_cast<const float4*>(imgw + e_hi);
+        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    // Persistent (two workgroups per CU draw tiles from a counter): Z, h, H~ of the NEXT tile's first 128 columns are requested before
+    // the last epilogue of the current one.  A freshly dispatched workgroup spent a third of a tile
+    // (22 k of 68 k cycles) waiting for those first loads -- HBM latency that nothing else of the workgroup could hide.
+    u32x4_t zr0[4], hr0[4], tr0[4];
+    auto request_tile0 = [&](long tile) {
+        const long m0 = tile * FT_ROWS;
+        const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+        const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<const char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
+        const __amdgpu_buffer_rsrc_t sH = f_rsrc(reinterpret_cast<const char*>(a.h) + m0 * C * 2, (long)nvalid * C * 2);
+        const __amdgpu_buffer_rsrc_t sHt = f_rsrc(reinterpret_cast<const char*>(a.Ht) + m0 * C * 2, (long)nvalid * C * 2);
+        // (offsets recomputed from an opaque copy of the lane's row / column: hoisted out of the tile loop they are spilled, and every
+        // reload waits for vmcnt(0) -- in the middle of this very burst of requests)
+        int er0 = er00, ec0 = ec00;
+        asm volatile("" : "+v"(er0), "+v"(ec0));
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            const int row = 16 * rnd + er0, c = ec0;
+            zr0[rnd] = __builtin_amdgcn_raw_buffer_load_b128(sZR, (row * 2 * C + c) * 2, 0, 0);
+            hr0[rnd] = __builtin_amdgcn_raw_buffer_load_b128(sH, (row * C + c) * 2, 0, 0);
+            tr0[rnd] = __builtin_amdgcn_raw_buffer_load_b128(sHt, (row * C + c) * 2, 0, 0);
+        }
+    };
+    long tile = blockIdx.x;
+    request_tile0(tile);
+#pragma unroll 1
+    while (tile < tiles) {
+    // (opaque per tile: hoisted out of the tile loop, the global / plane offsets derived from them stay live through every K loop)
+    asm volatile("" : "+v"(er), "+v"(ec));
+    const long m0 = tile * FT_ROWS;
+    const int nvalid = (int)(a.M - m0 < FT_ROWS ? a.M - m0 : FT_ROWS);
+    const unsigned mrow0 = (unsigned)m0;
+    const unsigned node0 = mrow0 / uT;
+    // The next tile comes from a counter in the workspace (zeroed by the launcher), not from blockIdx + k gridDim: when a kernel of
+    // the side stream holds some CUs the grid is not fully resident, and workgroups that start late would find a whole stride of
+    // tiles waiting for them (measured: 1.65 -> 2.4 ms with the head's weight gradients running beside this kernel).
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF) = a.tile_ctr ? atomicAdd(a.tile_ctr, 1u) + gridDim.x : (unsigned)(tile + gridDim.x);
     FB_MARK(0);
     // the tile's rows of every activation array; dOH from the tile's first node on (rows past the end read zeros, stores are dropped)
     const __amdgpu_buffer_rsrc_t sZR = f_rsrc(reinterpret_cast<const char*>(a.ZR) + m0 * C * 4, (long)nvalid * C * 4);
@@ -553,10 +612,6 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
     const __amdgpu_buffer_rsrc_t sdhp = f_rsrc(reinterpret_cast<char*>(a.dhp) + m0 * C * 2, (long)nvalid * C * 2);
     const __amdgpu_buffer_rsrc_t sdzr = f_rsrc(reinterpret_cast<char*>(a.dzr) + m0 * C * 4, (long)nvalid * C * 4);
     const __amdgpu_buffer_rsrc_t sdh = f_rsrc(reinterpret_cast<char*>(a.dh) + m0 * C * 2, (long)nvalid * C * 2);
-
-    float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF) + w * (FT_IMG_ROWS * FT_IMG_LD);
-    float* dotw = reinterpret_cast<float*>(flds + L::DOT_OFF);
-    const int er = lane >> 2, ec = 32 * w + 8 * (lane & 3);     // the lane's epilogue row of a round / first of its 8 columns of a tile
     float pt_[4];                                                // per round: attention probability of the lane's row,
     int dof_[4];                                                 //   byte offset of its node's dOH row behind node0's
 #pragma unroll
@@ -565,19 +620,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         pt_[rnd] = a.probs[m - nd * uT];
         dof_[rnd] = (int)(nd - node0) * C * 4;
     }
-    auto stage = [&](const f32x16 (&acc)[2], int rnd) {
-        const int mi = rnd >> 1, rd = rnd & 1;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int reg = 4 * (2 * rd + (q >> 2)) + (q & 3);
-            imgw[((q & 3) + 8 * (q >> 2) + 4 * lh) * FT_IMG_LD + lr] = mi ? acc[1][reg] : acc[0][reg];
-        }
-    };
-    auto img8 = [&]() {
-        const float4* p = reinterpret_cast<const float4*>(imgw + er * FT_IMG_LD + 8 * (lane & 3));
-        const float4 lo = p[0], hi = p[1];
-        return V8{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
-    };
+    __syncthreads();                                            // every wave is done with the planes and row dots of the previous tile
     auto plane_off = [&](int row, int c) { return (c >> 4) * L::PLANE_B + sp_off(row, (c >> 3) & 1); };
     auto ld16 = [&](__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); };
     auto ldd8 = [&](int off) {
@@ -585,17 +628,20 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         return V8{{__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(lo.z), __uint_as_float(lo.w),
                    __uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(hi.z), __uint_as_float(hi.w)}};
     };
-    // B fragments of one K = C product: column block nb of a transposed C x C weight block in fragment order
-    bf16x8 bw[KBC];
+    // B fragments: column block nb of a transposed C x C weight block in fragment order, HALF a K loop (8 of 16 blocks) in registers at
+    // a time -- a slot is refilled with the block eight further on (of this product, then of the next one) as soon as it has been
+    // multiplied.  (All 16 in registers cost 32 registers more: with the next tile's operands in flight the kernel spilled, and a
+    // spill reload waits for vmcnt(0), i.e. for the prefetch.)
+    bf16x8 bw[KBC / 2];
     auto issue_b = [&](const void* Wf, int nb, int from, int to) {
         const __amdgpu_buffer_rsrc_t sW = f_rsrc(Wf, (long)C * C * 2);
 #pragma unroll
         for (int kb = 0; kb < KBC; ++kb)
-            if (kb >= from && kb < to) bw[kb] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
+            if (kb >= from && kb < to) bw[kb % (KBC / 2)] = f_ldfrag(sW, lane * 16, (nb * KBC + kb) * 1024);
     };
-    // acc (+)= P (planes, K = C) x W^T with the fragments in bw; `Wnext` != nullptr: the two halves of bw are refilled with the
-    // fragments of (Wnext, nbnext) as soon as they have been multiplied (the second product of a K = 2C loop)
-    auto kloop = [&](f32x16 (&acc)[2], const char* P, bool zero, const void* Wnext, int nbnext) {
+    // acc (+)= P (planes, K = C) x Wcur^T; the first half of Wcur's fragments is in bw (requested by the previous K loop or by the
+    // caller), the second half follows the MFMAs of the first, then the first half of (Wnext, nbnext) follows the second (nullptr: none)
+    auto kloop = [&](f32x16 (&acc)[2], const char* P, bool zero, const void* Wcur, int nbcur, const void* Wnext, int nbnext) {
         if (zero) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -620,21 +666,24 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
                 fa[kb + AHEAD][1] = *reinterpret_cast<const bf16x8*>(pa1 + (kb + AHEAD) * L::PLANE_B);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], bw[kb], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], bw[kb], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][0], bw[kb % (KBC / 2)], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][1], bw[kb % (KBC / 2)], acc[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (Wnext && kb == KBC / 2 - 1) { issue_b(Wnext, nbnext, 0, KBC / 2); __builtin_amdgcn_sched_barrier(0); }
-            if (Wnext && kb == KBC - 1) { issue_b(Wnext, nbnext, KBC / 2, KBC); __builtin_amdgcn_sched_barrier(0); }
+            if (kb < KBC / 2) issue_b(Wcur, nbcur, kb + KBC / 2, kb + KBC / 2 + 1);
+            else if (Wnext) issue_b(Wnext, nbnext, kb - KBC / 2, kb - KBC / 2 + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     // ---- phase A: gate pre-activation gradients (element-wise): dhp -> global + planes P, dzp -> global ----------------------------
     float rdot[4] = {0.f, 0.f, 0.f, 0.f};
+    u32x4_t zkeep[NT][4];                    // Z as read in phase A: the dq epilogues need it again (dh = dq R + g Z) -- 32 registers
+                                             //   instead of a second read of the array (0.77 GB per step at the cfg-5 shard)
     {
         // every operand is requested before anything is stored (a load issued behind a store waits for that store): Z, h, H~ of both
         // column tiles up front, dOH of the second tile once the first tile's values are in registers, the stores after that
-        u32x4_t zr_[NT][4], hr_[NT][4], tr_[NT][4], o_p[4], o_z[4];
-        V8 dd_[4];
+        u32x4_t zr_[NT][4], hr_[NT][4], tr_[NT][4];
+        V8 dd_[NT][4];
         auto ld_zht = [&](int j) {
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
@@ -646,48 +695,46 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         };
         auto ld_d = [&](int j) {
 #pragma unroll
-            for (int rnd = 0; rnd < 4; ++rnd) dd_[rnd] = ldd8(dof_[rnd] + (128 * j + ec) * 4);
+            for (int rnd = 0; rnd < 4; ++rnd) dd_[j][rnd] = ldd8(dof_[rnd] + (128 * j + ec) * 4);
         };
-        ld_zht(0);
+        // (the first column tile's Z, h, H~ came with the previous tile; everything else this phase reads is requested now, before its
+        // first store -- a load issued behind a store waits for that store; the results are then stored round by round)
         ld_d(0);
         ld_zht(1);
+        ld_d(1);
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) { zr_[0][rnd] = zr0[rnd]; hr_[0][rnd] = hr0[rnd]; tr_[0][rnd] = tr0[rnd]; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
             for (int rnd = 0; rnd < 4; ++rnd) {
                 const V8 z = f_widen8(zr_[j][rnd]), h = f_widen8(hr_[j][rnd]), ht = f_widen8(tr_[j][rnd]);
+                zkeep[j][rnd] = zr_[j][rnd];
                 V8 dhp, dzp;
                 float dot = 0.f;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float g = __fmul_rn(pt_[rnd], dd_[rnd].v[i]);
+                    const float g = __fmul_rn(pt_[rnd], dd_[j][rnd].v[i]);
                     dhp.v[i] = cb_dhp(g, z.v[i], ht.v[i]);
                     dzp.v[i] = cb_dzp(g, h.v[i], ht.v[i], z.v[i]);
-                    dot += dd_[rnd].v[i] * (z.v[i] * h.v[i] + (1.0f - z.v[i]) * ht.v[i]);
+                    dot += dd_[j][rnd].v[i] * (z.v[i] * h.v[i] + (1.0f - z.v[i]) * ht.v[i]);
                 }
                 rdot[rnd] += dot;
                 asm volatile("" : "+v"(rdot[rnd]));              // the sum is formed here, not at its first use (keeps 1 - Z, h, H~ short-lived)
-                o_p[rnd] = f_pack8(dhp);
-                o_z[rnd] = f_pack8(dzp);
-                *reinterpret_cast<u32x4_t*>(Pp + plane_off(16 * rnd + er, 128 * j + ec)) = o_p[rnd];
+                const u32x4_t o_p = f_pack8(dhp), o_z = f_pack8(dzp);
+                const int row = 16 * rnd + er, c = 128 * j + ec;
+                *reinterpret_cast<u32x4_t*>(Pp + plane_off(row, c)) = o_p;
                 // h waits for the dq epilogue in the (still empty) planes R, at the very place the same lane will put drp
-                *reinterpret_cast<u32x4_t*>(Rp + plane_off(16 * rnd + er, 128 * j + ec)) = hr_[j][rnd];
+                *reinterpret_cast<u32x4_t*>(Rp + plane_off(row, c)) = hr_[j][rnd];
+                __builtin_amdgcn_raw_buffer_store_b128(o_p, sdhp, (row * C + c) * 2, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o_z, sdzr, (row * 2 * C + c) * 2, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (j + 1 < NT) ld_d(j + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rnd = 0; rnd < 4; ++rnd) {
-                const int row = 16 * rnd + er, c = 128 * j + ec;
-                __builtin_amdgcn_raw_buffer_store_b128(o_p[rnd], sdhp, (row * C + c) * 2, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o_z[rnd], sdzr, (row * 2 * C + c) * 2, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
     FB_MARK(1);
-    issue_b(a.UhTf, w, 0, KBC);                                  // dq, column tile 0
+    issue_b(a.UhTf, w, 0, KBC / 2);                              // dq, column tile 0: the first half of its fragments
 #pragma unroll
     for (int rnd = 0; rnd < 4; ++rnd) {                          // the wave's 32 columns x 2 tiles of row 16 rnd + er
         float s = rdot[rnd];
@@ -696,7 +743,13 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
         if ((lane & 3) == 0) dotw[w * FT_ROWS + 16 * rnd + er] = s;
     }
     __syncthreads();                                            // planes P (dhp) and the four waves' row dots complete
-    if (tid < nvalid) a.rowdot[m0 + tid] = (dotw[tid] + dotw[FT_ROWS + tid]) + (dotw[2 * FT_ROWS + tid] + dotw[3 * FT_ROWS + tid]);
+    const long tdrawn = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF));
+    const long tnext = tdrawn < tiles ? tdrawn : tiles - 1;     // (clamped for the prefetch: no branch around its loads)
+    if (tid < FT_ROWS) {                                        // (through a descriptor that ends with the tile's rows: no 64-bit address per lane)
+        const __amdgpu_buffer_rsrc_t sdot = f_rsrc(a.rowdot + m0, (long)nvalid * 4);
+        const float dsum = (dotw[tid] + dotw[FT_ROWS + tid]) + (dotw[2 * FT_ROWS + tid] + dotw[3 * FT_ROWS + tid]);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dsum), sdot, tid * 4, 0, 0);
+    }
 
     // ---- phase B: dq = dhp Uh2 per column tile; drp -> global + planes R, dh -> global (bf16: read back by the same lane in phase D,
     //      which is exactly the rounding point of the three-launch path) ----------------------------------------------------------------
@@ -707,19 +760,17 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {                               // (rolled: unrolled, the scheduler's hoisting costs ~1 KB of spills)
         unsigned hp = 0;
-        u32x4_t xz[2], xr[2];                                    // operands of the epilogue rounds, requested one round ahead
+        u32x4_t xr[2];                                           // operands of the epilogue rounds, requested one round ahead
         V8 xd[2];
         auto aux = [&](int rnd) {
             const int row = 16 * rnd + er, c = 128 * j + ec;
-            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);  // R: first touch (HBM); Z, dOH were read in phase A; h is in planes R
-            xz[rnd & 1] = ld16(sZR, (row * 2 * C + c) * 2);
+            xr[rnd & 1] = ld16(sZR, (row * 2 * C + C + c) * 2);  // R: first touch (HBM); Z waits in registers, h in planes R, dOH was read in phase A
             xd[rnd & 1] = ldd8(dof_[rnd] + c * 4);
         };
         aux(0);
         f32x16 acc[2];
-        kloop(acc, Pp, true, nullptr, 0);
-        if (j + 1 < NT) issue_b(a.UhTf, 4 * (j + 1) + w, 0, KBC);
-        else issue_b(a.UrTf, w, 0, KBC);                         // ds, column tile 0, first product
+        // (the next product's first fragments: dq of the next column tile, then ds of column tile 0)
+        kloop(acc, Pp, true, a.UhTf, 4 * j + w, j + 1 < NT ? a.UhTf : a.UrTf, j + 1 < NT ? 4 * (j + 1) + w : w);
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             if (rnd + 1 < 4) aux(rnd + 1);
@@ -727,7 +778,11 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
             const V8 v = img8();
             const int row = 16 * rnd + er, c = 128 * j + ec;
             const V8 h = f_widen8(*reinterpret_cast<const u32x4_t*>(Rp + plane_off(row, c)));
-            const V8 Z = f_widen8(xz[rnd & 1]), R = f_widen8(xr[rnd & 1]);
+            // (j is a run-time value in this rolled loop: a select, not a dynamic register index)
+            u32x4_t zsel;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zsel[i] = j == 0 ? zkeep[0][rnd][i] : zkeep[1][rnd][i];
+            const V8 Z = f_widen8(zsel), R = f_widen8(xr[rnd & 1]);
             V8 drp, dh;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -763,7 +818,7 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
                 for (int rnd = 0; rnd < 4; ++rnd) dzk[jj][rnd] = ld16(sdzr, ((16 * rnd + er) * 2 * C + 128 * jj + ec) * 2);
         }
         f32x16 acc[2];
-        kloop(acc, Rp, true, a.UzTf, 4 * j + w);
+        kloop(acc, Rp, true, a.UrTf, 4 * j + w, a.UzTf, 4 * j + w);
         if (j == 0) FB_MARK(4);
         if (j == 0) {
 #pragma unroll
@@ -772,8 +827,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
                 for (int rnd = 0; rnd < 4; ++rnd) *reinterpret_cast<u32x4_t*>(Pp + plane_off(16 * rnd + er, 128 * jj + ec)) = dzk[jj][rnd];
             __syncthreads();                                    // planes P (dzp) complete
         }
-        kloop(acc, Pp, false, nullptr, 0);
-        if (j + 1 < NT) issue_b(a.UrTf, 4 * (j + 1) + w, 0, KBC);
+        kloop(acc, Pp, false, a.UzTf, 4 * j + w, j + 1 < NT ? a.UrTf : nullptr, 4 * (j + 1) + w);
+        if (j + 1 == NT) request_tile0(tnext);                   // the next tile's first operands, before this tile's last stores
 #pragma unroll
         for (int rnd = 0; rnd < 4; ++rnd) {
             stage(acc, rnd);
@@ -788,6 +843,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b128(f_pack8(o), sdh, ((16 * rnd + er) * C + 128 * j + ec) * 2, 0, 0);
         }
         FB_MARK(5 + j);
+    }
+    tile = tdrawn;
     }
 #undef FB_MARK
 }
@@ -805,7 +862,9 @@ int launch_fused_backward(const FusedBwdArgs& a_, int C, hipStream_t st) {
         REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_bwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL((fused_bwd_kernel<256>), dim3((unsigned)tiles), dim3(256), L::BYTES, st, a);
+    const long slots = 2L * fused_cus();                        // persistent: two workgroups per CU
+    if (a.tile_ctr) REGT_CHECK_HIP(hipMemsetAsync(a.tile_ctr, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL((fused_bwd_kernel<256>), dim3((unsigned)(tiles < slots ? tiles : slots)), dim3(256), L::BYTES, st, a);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -843,6 +902,7 @@ int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
     // persistent: two workgroups per CU (what LDS and registers admit), each walks its tiles with a stride of the grid
     const long slots = 2L * fused_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    if (a.tile_ctr) REGT_CHECK_HIP(hipMemsetAsync(a.tile_ctr, 0, sizeof(unsigned), st));
     if (F == 64) hipLaunchKernelGGL((fused_fwd_kernel<256, 64>), dim3(grid), dim3(256), L::BYTES, st, a);
     else hipLaunchKernelGGL((fused_fwd_kernel<256, 32>), dim3(grid), dim3(256), L::BYTES, st, a);
     REGT_CHECK_LAUNCH();

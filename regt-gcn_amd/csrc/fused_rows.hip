@@ -41,7 +41,8 @@ struct FusedRowsLds {
     static constexpr int BIAS_OFF = 0;
     static constexpr int IMG_OFF = BIAS_OFF + 4 * FR_C * 4;
     static constexpr int RING_OFF = IMG_OFF + 8 * FR_IMG_B;
-    static constexpr int BYTES = RING_OFF + FR_SLOTS * FR_SLICE_B;
+    static constexpr int NEXT_OFF = RING_OFF + FR_SLOTS * FR_SLICE_B;   // the workgroup's next tile (drawn from the tile counter)
+    static constexpr int BYTES = NEXT_OFF + 16;
 };
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -317,16 +318,17 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
 
 #pragma unroll 1
-    for (; tile < tiles; tile += gridDim.x) {
+    while (tile < tiles) {
+        // (the next tile is drawn from a counter in the workspace, not blockIdx + k gridDim: workgroups that start late -- a kernel of
+        // the side stream holding their CU -- must not find a whole stride of tiles waiting for them; read behind the ring's barriers)
+        if (tid == 0) *reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF) = a.tile_ctr ? atomicAdd(a.tile_ctr, 1u) + gridDim.x : (unsigned)(tile + gridDim.x);
         const long m0 = tile * FR_ROWS + 16 * v;                 // the wave's first row
         const long left = a.M - m0;
         const int nv = (int)(left < 0 ? 0 : (left < 16 ? left : 16));      // its valid rows
         const unsigned mrow0 = (unsigned)m0;
         const unsigned node0 = mrow0 / uT;
         const int t0 = (int)(mrow0 - node0 * uT);
-        const long tnext = tile + gridDim.x;
-        const FrTileInfo info_next = tile_info(tnext);
-        rg_cur = info.rg_first; rg_nxt = info_next.rg_first; has_next = tnext < tiles;
+        rg_cur = info.rg_first;
         // (opaque per tile: left alone, hipcc hoists the source addresses of all 75 request sites out of the tile loop -- 150 scalar
         // registers, spilled to vector lanes)
         asm volatile("" : "+s"(voff_c), "+s"(voff_f));
@@ -396,6 +398,9 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         };
         unit_embed(std::integral_constant<int, 0>{});
         unit_embed(std::integral_constant<int, 1>{});
+        const long tnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF));
+        const FrTileInfo info_next = tile_info(tnext);           // (first used by the requests that reach into the next tile: the last FR_AHEAD slices)
+        rg_nxt = info_next.rg_first; has_next = tnext < tiles;
         // ---- reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R: the candidate's A operand --------------------------------
         // (a generic lambda over a constant j, not a loop: the bodies are too long for hipcc to unroll, and every index must be static)
         auto unit_r = [&](auto jc) {
@@ -514,6 +519,7 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         unit_zc(std::integral_constant<int, 0>{});
         unit_zc(std::integral_constant<int, 1>{});
         first_tile = false;
+        tile = tnext;
     }
     // (the ring holds no request any more: the producer stopped with the last tile's last slice, which has been consumed)
 #undef FT_MARK
@@ -557,6 +563,7 @@ int launch_fused_forward_rows(const FusedFwdArgs& a_, int C, int F, hipStream_t 
     // persistent: one workgroup of eight waves per CU
     const long slots = fused_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    if (a.tile_ctr) REGT_CHECK_HIP(hipMemsetAsync(a.tile_ctr, 0, sizeof(unsigned), st));
     if (F == 64) hipLaunchKernelGGL((fused_fwd_rows_kernel<64>), dim3(grid), dim3(512), L::BYTES, st, a);
     else hipLaunchKernelGGL((fused_fwd_rows_kernel<32>), dim3(grid), dim3(512), L::BYTES, st, a);
     REGT_CHECK_LAUNCH();

@@ -266,6 +266,7 @@ struct FusedFwdArgs {
     long M; int T; float slope; int act_lrelu;
     long nodes;                               // M / T                                            } filled in by launch_fused_forward
     unsigned long long pmask;                 // bit k T for every k T < 64 (rows that start a node) }
+    unsigned* tile_ctr;                       // workspace word (zeroed by the launcher): the persistent workgroups draw their tiles from it
     const char* wbase;                        // fused_rows.hip: the weight blocks as 32-bit offsets from one base (filled in by its launcher)
     unsigned o_uz, o_ur, o_uh, o_gzr, o_gh, o_a0, o_aall;
     int dbg;                                  // timing-only switches (REGT_FUSED_DBG, fused.hip); 0 in normal operation
@@ -285,6 +286,7 @@ struct FusedBwdArgs {
     const void *UhTf, *UzTf, *UrTf;           // TRANSPOSED h-halves of linear_h / _z / _r (C x C) in MFMA fragment order
     void *dhp, *dzr, *dh;                     // bf16 outputs: (M x C), (M x 2C) = [dzp | drp], (M x C) = ds
     float* rowdot;                            // (M) fp32: <dOH[node], H'[m]> per row (attention-probability gradient, summed later)
+    unsigned* tile_ctr;                       // workspace word (zeroed by the launcher): the persistent workgroups draw their tiles from it
     long M; int T; float slope; int act_lrelu;
     long* trace;                              // developer trace buffer (REGT_FUSED_TRACE=2) or nullptr
 };
