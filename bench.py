@@ -61,6 +61,8 @@ WORKLOADS = {
     # BASELINE configs[4] = 8 of these: 1M nodes / 10M edges / 64 regions / F=64, bf16 GEMM operands, fp32 accumulate
     "cfg5": dict(nodes=125_000, edges=1_250_000, regions=8, F=64, T=12, O=1, mode=2, dtype="bf16", scaling="weak"),
     "cfg5shard": dict(nodes=125_000, edges=1_250_000, regions=8, F=64, T=12, O=1, mode=2, dtype="bf16", scaling="weak"),
+    # BASELINE configs[4] WHOLE on one GPU (the N = 1 anchor of its scaling curve): 1M nodes / 10M edges / 64 regions / F = 64, bf16
+    "cfg5full": dict(nodes=1_000_000, edges=10_000_000, regions=64, F=64, T=12, O=1, mode=2, dtype="bf16", scaling="strong"),
 }
 MODE_NAMES = {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 1: "exact 3-way bf16 split, 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate",
               2: "bf16 operands (RNE at LDS staging), v_mfma_f32_32x32x16_bf16, fp32 accumulate"}
@@ -314,6 +316,27 @@ def cfg5shard_leg(args):
         leg = json.loads(line[-1])
         leg.pop("stages", None)          # the per-stage table of the leg: `python bench.py --workload cfg5shard` prints it
         return leg
+    except Exception as e:               # a secondary leg must never take the headline line down
+        return {"error": repr(e)}
+
+
+def cfg5full_leg(args):
+    """BASELINE.json configs[4] WHOLE on one MI355X (1 000 000 nodes / 10 000 000 edges / 64 regions / F = 64, bf16): the N = 1 anchor
+    of its scaling curve, as a child process (own library state, own peak-memory figure).  Secondary leg: never the headline value."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cfg5full", "--steps", str(min(args.steps, 10)), "--warmup", str(min(args.warmup, 2)),
+           "--no-cpu-baseline", "--no-split-leg", "--no-tpims-leg", "--no-cfg5-leg"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        leg = json.loads(line[-1])
+        keep = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "n_gpus") if k in leg}
+        keep["workload"] = leg["config"]["workload"]
+        keep["peak_memory_gb"] = leg["config"].get("peak_memory_gb")
+        keep["top_stages_ms"] = {k: round(v["avg_ms"], 4) for k, v in sorted(leg.get("stages", {}).items(), key=lambda kv: -kv[1]["avg_ms"])[:8]}
+        return keep
     except Exception as e:               # a secondary leg must never take the headline line down
         return {"error": repr(e)}
 
@@ -657,6 +680,7 @@ def main():
                        "global_nodes": gnodes, "global_edges": gedges, "global_regions": gregions,
                        "parallelism": "single GPU" if world == 1 else f"region-sharded x{world}: halo-row all-to-all per step (one step ahead, side stream) + 1 grad all-reduce",
                        "final_loss": final_loss,
+                       "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
                        "device_allocs_in_timed_region": allocs_timed},
         }
         if world > 1 or force_shard:
@@ -734,6 +758,7 @@ def main():
             out["tpims_configs1"] = tpims
         if world == 1 and args.workload == "cfg3" and not args.no_cfg5_leg and not force_shard:
             out["cfg5shard_configs4"] = cfg5shard_leg(args)
+            out["cfg5full_configs4_one_gpu"] = cfg5full_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             if shard_of_8:
                 # the reference formulation materialises an (N, R*C) concat: 8.2 GB per period at 125k nodes x 64 regions, so

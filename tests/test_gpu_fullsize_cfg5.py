@@ -191,3 +191,68 @@ def test_shard_full_configuration_identical_periods_property(R, world, mode):
             if k == "tgnn._attention":
                 continue
             assert float((g12[k] - g_f[k]).norm()) <= 8 * BF16_U * float(g_f[k].norm()) + 1e-9, k
+
+
+# ---- BASELINE configs[4] at full size on ONE GPU: the whole 1 M-node graph against its eight shards ---------------------------------
+# The N = 1 anchor of the scaling curve (bench.py --workload cfg5full) and all eight ranks' shards (different halo counts, the last
+# region block), executed one after the other as tests/test_gpu_fullsize.py does for configs[3]: every owned prediction / hidden row
+# of a shard must equal the whole-graph run's, the gradients summed over the ranks (= the all-reduce) its gradients -- within the 8 u
+# bar of the bf16 arithmetic (tile boundaries differ between the two runs, so operands can round the other way).
+def test_configs4_whole_graph_on_one_gpu_equals_its_eight_shards_bf16(R):
+    lib = R.load_library()
+    t = 12
+    g = R.data.synthetic_regional_graph(GN, GE, GR, seed=42)
+    (x, y), = R.data.synthetic_snapshots(GN, F, t, O, 1, seed=31)
+    p = M.init_params("RegionalTemporalGCN", F, t, O, num_nodes=GN, num_regions=GR, seed=32)
+    prev = lib.regt_set_gemm_mode(2)
+    try:
+        def fresh():
+            m = R.RegionalTemporalGCN(F, GN, t, O, num_regions=GR)
+            m.load_state_dict(p)
+            return m.cuda()
+
+        full = fresh()
+        pg = full.prepare_graph(g.edge_index.cuda(), [i.cuda() for i in g.region_index], [a.cuda() for a in g.region_attr])
+        assert pg.region_sorted
+        torch.cuda.reset_peak_memory_stats()
+        pred_f, hid_f = full.forward_prepared(x.cuda(), pg)
+        (((pred_f - y.cuda()) ** 2).sum() / (GN * O)).backward()
+        torch.cuda.synchronize()
+        peak_gb = torch.cuda.max_memory_allocated() / 1e9
+        assert peak_gb < 250, peak_gb                                     # the whole configs[4] step fits one 288 GB part
+        pred_f, hid_f = pred_f.detach(), hid_f.detach()
+        assert bool(torch.isfinite(pred_f).all()) and bool(torch.isfinite(hid_f).all())
+        grads_f = {k: q.grad.clone() for k, q in full.named_parameters() if q.grad is not None}
+        del full, pg
+        torch.cuda.empty_cache()
+
+        sharded = fresh()
+        rpg = GR // WORLD
+        bounds = np.asarray(g.region_bounds[::rpg], dtype=np.int64)
+        owner = [r // rpg for r in range(GR)]
+        xp_glob = R.ops.pack_x(x.cuda()).view(GN, t * F)
+        hscale, pscale = float(hid_f.abs().max()), float(pred_f.abs().max())
+        worst_pred = worst_hid = 0.0
+        halo_rows = []
+        for rank in range(WORLD):
+            sh = R.dist.build_shard(g.edge_index, g.region_index, g.region_attr, GN, bounds, owner, rank, WORLD, "cuda")
+            lo, hi = sh.topo.node_lo, sh.topo.node_hi
+            assert sh.graph.region_lo == rank * rpg and sh.graph.region_hi == (rank + 1) * rpg
+            halo_rows.append(sh.topo.halo_rows)
+            xp = torch.empty(sh.topo.x_rows, t * F, device="cuda")
+            xp[:hi - lo] = xp_glob[lo:hi]
+            xp[hi - lo:] = xp_glob[torch.from_numpy(sh.topo.halo_ids()).cuda()]
+            pred, hid = sharded.forward_packed(xp.view(sh.topo.x_rows, t, F), sh.graph)
+            worst_pred = max(worst_pred, float((pred.detach() - pred_f[lo:hi]).abs().max()))
+            worst_hid = max(worst_hid, float((hid.detach() - hid_f[lo:hi]).abs().max()))
+            (((pred - y[lo:hi].cuda()) ** 2).sum() / (GN * O)).backward()              # .grad accumulates = all-reduce(sum)
+            del sh, xp, pred, hid
+        assert all(30_000 < h < 80_000 for h in halo_rows), halo_rows      # ~53 000 halo rows per 125 000-node shard
+        assert worst_hid < 8 * BF16_U * hscale and worst_pred < 8 * BF16_U * pscale, (worst_pred, worst_hid, hscale, pscale)
+        grads_s = {k: q.grad for k, q in sharded.named_parameters() if q.grad is not None}
+        assert set(grads_s) == set(grads_f)
+        for k in grads_f:
+            a, b = grads_s[k].double().cpu(), grads_f[k].double().cpu()
+            assert float((a - b).norm()) <= 8 * BF16_U * float(b.norm()) + 1e-9, k
+    finally:
+        lib.regt_set_gemm_mode(prev)
