@@ -280,6 +280,23 @@ struct Layout {
     size_t bytes;
 };
 
+// Row chunks of the head's two weight gradients (N rows -- nodes, not node x period rows).  Rounds 1-4 gave both max(512, N / 64)-row
+// chunks: 64 workgroups for dW2 (a latency-bound serial walk: 199 us for 51 MB at cfg-3) and 128 for dW1 -- and at one region per
+// GPU (12 500 rows) 25 chunks, fewer workgroups than at twice the rows.  Now: dW2 ~1000 chunks of >= 64 rows (its slabs are O x H1
+// floats), dW1 ~three workgroups per CU with >= 128 rows per chunk (its slabs are H1 x C floats: more chunks = more slab traffic).
+struct HeadChunks { int k1, n1, k2, n2; };
+HeadChunks head_chunks(long N, int H1, int C) {
+    HeadChunks h;
+    long k2 = ((N + 1023) / 1024 + 7) / 8 * 8;
+    if (k2 < 64) k2 = 64;
+    h.k2 = (int)k2; h.n2 = (int)((N + k2 - 1) / k2);
+    const long tiles = (long)((H1 + 127) / 128) * ((C + 127) / 128), want = 768 / (tiles > 0 ? tiles : 1);
+    long k1 = ((N + want - 1) / (want > 0 ? want : 1) + 31) / 32 * 32;
+    if (k1 < 128) k1 = 128;
+    h.k1 = (int)k1; h.n1 = (int)((N + k1 - 1) / k1);
+    return h;
+}
+
 Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base) {
     Layout L{};
     const long N = d.N, T = d.T, F = d.F, C = d.C, R = d.R, O = d.O, H1 = d.H1;
@@ -349,7 +366,7 @@ Layout make_layout(const regt_dims& d, int n_chunks_tab, int overlap, char* base
     auto nmax = [&](long layout_chunks, int nout, int nin) { const long b = wgrad_chunk_bound(nout, nin, M); return b > layout_chunks ? b : layout_chunks; };
     long slab = nmax(L.nchunks, C, C + F) * ((long)C * (C + F) + C) + nmax(L.nchunks, 2 * C, C + F) * (2L * C * (C + F) + 2 * C)
               + nmax(L.nchunks_s, C, F) * (C * F) + nmax(L.nchunks_s, 2 * C, F) * (2 * C * F) + (long)L.nchunks_s * (C * F + C)
-              + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64
+              + (long)head_chunks(N, (int)H1, (int)C).n1 * (H1 * C + H1 + O * H1 + O) + (long)head_chunks(N, (int)H1, (int)C).n2 * (O * H1 + O) + 8 * 64
               + nmax(L.nchunks_s, 2 * C, 2 * F) * (2 * C * 2 * F + 2 * C) + 64;   // FMT_TCOLLAPSE: dzr^T [x | L~ x] (one or two launches)
     const long ar_uniform = (long)L.nchunks_s * C * F, ar_tab = (long)(n_chunks_tab > 0 ? n_chunks_tab : 1) * C * F;
     slab += ar_tab > ar_uniform ? ar_tab : ar_uniform;
@@ -778,13 +795,16 @@ int wgrad_full(ReduceQueue& q, const char* name, const float* P, long ldp, int N
 // backward of head_forward: weight / bias gradients of linear2 and linear1 (slabs queued on `rq`) and
 // dOH = (d1 A1) * (hidden > 0) + dhidden, the gradient of the attention-weighted hidden state
 int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr, const float* dpred, const float* dhidden,
-                  const float* hidden, const float* y1, float* d1, float* dOH, int kchunk_head, int nchunks_head,
+                  const float* hidden, const float* y1, float* d1, float* dOH, int kchunk_head_unused, int nchunks_head_unused,
                   ReduceQueue& rq, hipStream_t st) {
     const int N = d.N, C = d.C, O = d.O, H1 = d.H1;
+    (void)kchunk_head_unused; (void)nchunks_head_unused;
+    const HeadChunks hc = head_chunks(N, H1, C);
+    const int kchunk_head = hc.k1, nchunks_head = hc.n1;
     const bool skinny = head2_skinny_ok(H1, O, y1, p.head2_w);
     if (skinny) {
         float* slab = nullptr;
-        TRY(rq.take((long)nchunks_head * ((long)O * H1 + O), &slab));
+        TRY(rq.take((long)hc.n2 * ((long)O * H1 + O), &slab));
         {   // d1 first: the weight gradients leave the critical path behind it (side stream)
             PROF("head_bwd", st);
             TRY(launch_head2_bwd(dpred, p.head2_w, y1, d1, N, H1, O, st));
@@ -792,10 +812,10 @@ int head_backward(const regt_dims& d, const regt_params& p, const regt_grads& gr
         hipStream_t ss = side_fork(st);
         {
             PROF("wgrad_head2", ss);
-            TRY(launch_head2_wgrad(dpred, y1, slab, N, H1, O, kchunk_head, nchunks_head, 1, ss));
+            TRY(launch_head2_wgrad(dpred, y1, slab, N, H1, O, hc.k2, hc.n2, 1, ss));
         }
         WgradReduceArgs r{};
-        r.slab = slab; r.nchunks = nchunks_head; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
+        r.slab = slab; r.nchunks = hc.n2; r.slab_stride = (long)O * H1 + O; r.elem_offset = 0;
         r.Nout = O; r.Nin = H1; r.chunk_group = nullptr; r.ngroups = 1; r.out = gr.head2_w; r.ldo = H1; r.group_stride = 0;
         r.colsum_out = gr.head2_b; r.colsum_offset = (long)O * H1; r.ncolsum = O; r.accumulate = 0;
         TRY(rq.push(r));
@@ -1491,7 +1511,7 @@ Layout0 make_layout0(const regt_dims& d, int kz, int kh, char* base) {
     L.cb_npb = (L.cb_npb + 3) / 4 * 4;
     L.cb_blocks = cell_bwd_blocks((int)N, L.cb_npb);
     L.dp_partial = take((long)L.cb_blocks * T);
-    L.slab_floats = (long)L.nchunks * (C * kz + C) + (long)L.nchunks * (C * kh + C) + (long)L.nchunks_head * (H1 * C + H1 + O * H1 + O) + 8 * 64;
+    L.slab_floats = (long)L.nchunks * (C * kz + C) + (long)L.nchunks * (C * kh + C) + (long)head_chunks(N, (int)H1, (int)C).n1 * (H1 * C + H1 + O * H1 + O) + (long)head_chunks(N, (int)H1, (int)C).n2 * (O * H1 + O) + 8 * 64;
     L.slab = take(L.slab_floats);
     L.bytes = off;
     return L;
