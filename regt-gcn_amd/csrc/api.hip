@@ -199,7 +199,7 @@ enum : int { FMT_QBF = 1, FMT_XBF = 2, FMT_XCALLER = 4, FMT_TCOLLAPSE = 8 };
 // REGT_TGCN_COLLAPSE=0 / regt_set_option("tgcn_collapse", 0): the uncollapsed form (A/B, tests).
 int g_opt_wgrad_pairs = -1;
 int wgrad_pairs_setting() {
-    if (g_opt_wgrad_pairs < 0) { const char* e = getenv("REGT_WGRAD_PAIRS"); g_opt_wgrad_pairs = e ? (atoi(e) ? 1 : 0) : 2; }
+    if (g_opt_wgrad_pairs < 0) g_opt_wgrad_pairs = 2;
     return g_opt_wgrad_pairs;
 }
 int g_opt_tcollapse = -1;
@@ -965,9 +965,7 @@ int backward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p,
     // The (C x F)-sized gradients (Gh, Gzr, A0 | A_r) are HBM-bound -- they stream dhp / dzp|drp / ds for a K = F..2F product --
     // while the two big ones (Uh, Uzr) sit on the matrix pipe: REGT_SIDE_WGRADS=1 issues the former on the side stream so that
     // the two kinds overlap (A/B switch; see DESIGN.md section 6 for the measurement).
-    static int side_wgrads = -1;
-    if (side_wgrads < 0) { const char* e = getenv("REGT_SIDE_WGRADS"); side_wgrads = e ? atoi(e) : 0; }
-    hipStream_t sw = side_wgrads ? side_fork(st) : st;
+    hipStream_t sw = st;        // (the skinny weight gradients on the side stream: measured noise, round 3 -- the switch is gone)
     // ---- weight gradients of the K=C contractions and of the composed (C,F) weights -----------------
     // bf16 rows (fused kernels' layout): dUh | dGh = dhp^T [q | A_hat x] and dUzr | dGzr = dzr^T [h | A_hat x] as ONE launch each -- the
     // A_hat x part is a third column tile of the same row chunk on the same XCD, so dhp / dzp|drp cross HBM once instead of twice.

@@ -880,10 +880,8 @@ long fused_trace_fetch(long* out, long capacity) {
 }
 int launch_fused_forward(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
     REGT_CHECK_ARG(a_.M > 0 && a_.T > 0, "fused forward: empty problem");
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("REGT_FUSED_DBG"); dbg = e ? atoi(e) : 0; }
     FusedFwdArgs a = a_;
-    a.dbg = dbg;
+    a.dbg = 0;                  // (timing-only descriptor switches of the kernel: developer builds set them, see tools/fused_ablation.sh)
     REGT_CHECK_ARG(a.M % a.T == 0, "fused forward: M = %ld rows are no whole number of T = %d periods", a.M, a.T);
     a.nodes = a.M / a.T;
     a.pmask = 0;

@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256, 3) void gemm_flat_split_kernel(GemmSegs S, lon
 // dgrad_candidate with its left operand generated on the way (SplitCore::run_u_gen + EpiDgrad1GenF): cell_bwd_kernel and the candidate
 // data gradient in one launch.  fp32 arithmetic; two workgroups per CU (three operand arrays in flight per A slot).
 template <int NP>     // 0: fp32 MFMA; 3: exact bf16x3 split (REGT_GEMM_MODE=bf16x3) -- fp32 storage either way
-__global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi, int rotate) {
+__global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, long M, int N, EpiDgrad1GenF epi) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tiles_n = (N + GBN - 1) / GBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -879,10 +879,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dgrad1_gen_kernel(GemmSegs S, lon
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const typename SplitCore<false, NP>::AGen g{epi.e.ZR, epi.e.Ht, epi.e.dOH, epi.e.dhp, epi.e.C, (unsigned)epi.e.num_nodes * (unsigned)epi.e.C * 4u};
-    // k walk of this column tile: natural order (rotate = 1, an experiment that lost: start behind the tile's own columns)
-    const int nslab = epi.e.C / GBK;
-    const int rot = rotate ? ((n0 + GBN) / GBK) % nslab : 0;
-    core.run_u_gen(acc, g, rot);
+    core.run_u_gen(acc, g);
     core.for_each_vec_halves(acc, epi);
 }
 
@@ -1038,9 +1035,7 @@ constexpr long SMALL_TILE_LIMIT = 128;
 
 template <class EpiF, bool BT, bool REGION>
 static int launch_fast(const GemmSegs& S, long M, int N, EpiF f, int relu, hipStream_t st) {
-    static int force_small = -1;
-    if (force_small < 0) { const char* e = getenv("REGT_SMALL_TILES"); force_small = e ? atoi(e) : 0; }
-    if (gemm_mode() == 0 && (force_small || (long)cdiv(M, GBM) * cdiv(N, GBN) < SMALL_TILE_LIMIT)) {
+    if (gemm_mode() == 0 && (long)cdiv(M, GBM) * cdiv(N, GBN) < SMALL_TILE_LIMIT) {
         const long tiles = (long)cdiv(M, SM_B) * cdiv(N, SM_B);
         hipLaunchKernelGGL((gemm_flat_small_kernel<EpiF, BT, REGION>), dim3((unsigned)tiles), dim3(256), SM_LDS_BYTES, st, S, M, N, f,
                            relu);
@@ -1141,26 +1136,26 @@ static bool dgrad1_gen_wanted() {
 // ahead kernel wgrad_split_kernel<1, true, true>: same slabs bit for bit) | 4 | 6 | 8 half slabs of lead.
 static int g_wgrad_ring = -1;
 static int wgrad_ring_depth() {
-    if (g_wgrad_ring < 0) { const char* e = getenv("REGT_WGRAD_RING"); g_wgrad_ring = e ? atoi(e) : 6; }
+    if (g_wgrad_ring < 0) g_wgrad_ring = 6;
     return g_wgrad_ring;
 }
 static int g_wgrad_ring256 = -1;
 int wgrad_ring256_option(int value) {      // ring depth of the 256-row tile variant: 2 (default) | 4; -1 = query
-    if (g_wgrad_ring256 < 0) { const char* e = getenv("REGT_WGRAD_RING256"); g_wgrad_ring256 = e && atoi(e) == 4 ? 4 : 2; }
+    if (g_wgrad_ring256 < 0) g_wgrad_ring256 = 2;
     const int prev = g_wgrad_ring256;
     if (value >= 0) g_wgrad_ring256 = value == 4 ? 4 : 2;
     return prev;
 }
 static int g_wgrad_bnw64 = -1;
 int wgrad_bnw64_option(int value) {      // regt_set_option("wgrad_bnw64", 0 | 1); -1 = query
-    if (g_wgrad_bnw64 < 0) { const char* e = getenv("REGT_WGRAD_BNW64"); g_wgrad_bnw64 = e ? (atoi(e) ? 1 : 0) : 1; }
+    if (g_wgrad_bnw64 < 0) g_wgrad_bnw64 = 1;
     const int prev = g_wgrad_bnw64;
     if (value >= 0) g_wgrad_bnw64 = value ? 1 : 0;
     return prev;
 }
 static int g_wgrad_tile = -1;
 static int wgrad_tile_rows() {
-    if (g_wgrad_tile < 0) { const char* e = getenv("REGT_WGRAD_TILE"); g_wgrad_tile = e && atoi(e) == 128 ? 128 : 256; }
+    if (g_wgrad_tile < 0) g_wgrad_tile = 256;
     return g_wgrad_tile;
 }
 int wgrad_tile_option(int value) {
@@ -1177,7 +1172,7 @@ bool wgrad_ring_active() { return wgrad_ring_depth() > 0; }
 // REGT_WGRAD_WAVE=0 / regt_set_option("wgrad_wave", 0): the layout's ~128 chunks.  false: not applicable, keep the caller's chunking.
 static int g_wgrad_wave = -1;
 int wgrad_wave_option(int value) {
-    if (g_wgrad_wave < 0) { const char* e = getenv("REGT_WGRAD_WAVE"); g_wgrad_wave = e ? (atoi(e) ? 1 : 0) : 1; }
+    if (g_wgrad_wave < 0) g_wgrad_wave = 1;
     const int prev = g_wgrad_wave;
     if (value >= 0) g_wgrad_wave = value ? 1 : 0;
     return prev;
@@ -1188,7 +1183,7 @@ int wgrad_wave_option(int value) {
 // (profiles/r04_wgrad_wave32_ab.txt).  REGT_WGRAD_WAVE32=0: the layout's chunks; =2: two waves (more slabs to reduce: slower).
 static int g_wgrad_wave32 = -1;
 bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
-    if (g_wgrad_wave32 < 0) { const char* e = getenv("REGT_WGRAD_WAVE32"); g_wgrad_wave32 = e ? atoi(e) : 1; }
+    if (g_wgrad_wave32 < 0) g_wgrad_wave32 = 1;
     if (!g_wgrad_wave32 || gemm_mode() == 2 || fp32_core_wide() || Nin <= 32) return false;
     static int cus = 0;
     if (!cus) {
@@ -1212,9 +1207,7 @@ bool wgrad_wide_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
 // Skinny gradients (Nin <= 32: wgrad_kernel<32>, HBM-bound on their left operand): chunks x row tiles = REGT_WGRAD_SKINNY (default 2)
 // workgroups per CU, all resident at once -- at cfg-3 the layout's 507 chunks are 1.3 (dGh) / 2.6 (dGzr) waves of workgroups.
 bool wgrad_skinny_chunking(int Nout, long M, int* kchunk, int* nchunks) {
-    static int per_cu = -1;
-    if (per_cu < 0) { const char* e = getenv("REGT_WGRAD_SKINNY"); per_cu = e ? atoi(e) : 2; }
-    if (per_cu <= 0) return false;
+    constexpr int per_cu = 2;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -1260,9 +1253,7 @@ bool wgrad_ring_chunking(int Nout, int Nin, long M, int* kchunk, int* nchunks) {
 long wgrad_chunk_bound(int Nout, int Nin, long M) {
     int cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    int skinny = 2, wave32 = 1;
-    if (const char* e = getenv("REGT_WGRAD_SKINNY")) skinny = atoi(e) > skinny ? atoi(e) : skinny;
-    if (const char* e = getenv("REGT_WGRAD_WAVE32")) wave32 = atoi(e) > wave32 ? atoi(e) : wave32;
+    const int skinny = 2, wave32 = 1;
     const long cand[3] = {(long)cus * 3 * wave32 / ((long)cdiv(Nout, 128) * cdiv(Nin, 128)),      // wide fp32 / bf16x3, ring (128-row tiles)
                           (long)cus * skinny / cdiv(Nout, 128),                                   // skinny
                           (long)cus * 3 / ((long)cdiv(Nout, 256) > 0 ? (long)cdiv(Nout, 256) * cdiv(Nin, 128) : 1)};
@@ -1303,12 +1294,10 @@ int launch_gemm_dgrad1_gen(const GemmSegs& S, long M, int N, const EpiDgrad1& e,
     REGT_CHECK_ARG(a16(e.h) && a16(e.ZR) && a16(e.dOH) && a16(e.dzr) && a16(e.dh) && a16(e.Ht) && a16(e.dhp), "dgrad1 (generated operand): 16-byte aligned arrays");
     const long tiles = (long)cdiv(M, GBM) * (N / GBN);
     REGT_CHECK_ARG(tiles < (1L << 31), "gemm: too many tiles");
-    static int rotate = -1;
-    if (rotate < 0) { const char* r = getenv("REGT_DGRAD1_ROT"); rotate = r ? atoi(r) : 0; }
     if (gemm_mode() == 1)
-        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<3>, dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
+        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<3>, dim3((unsigned)tiles), dim3(256), SplitGeom<3>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN});
     else
-        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<0>, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN}, rotate);
+        hipLaunchKernelGGL(gemm_dgrad1_gen_kernel<0>, dim3((unsigned)tiles), dim3(256), SplitGeom<0>::LDS_BYTES, st, S, M, N, EpiDgrad1GenF{e, e.C / GBN});
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -2895,15 +2884,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel_generic(WgradArgs a) {
 long wgrad_slab_stride(const WgradArgs& a) { return (long)a.Nout * a.Nin + (a.colsum ? a.Nout : 0); }
 
 static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st);
-// Every column tile of a row chunk forms the column sums of P although only tile 0 stores them (REGT_WGRAD_SYM=0: tile 0 alone):
+// Every column tile of a row chunk forms the column sums of P although only tile 0 stores them:
 // the tiles of a chunk share P (and Q between row tiles) through their XCD's L2 and only find each other's lines there while they walk
 // the chunk in step -- with less work the other tiles run ahead and every tile reads its operands from HBM (measured on the bf16
 // ring kernel: 0.90 / 0.51 ms against 0.71 / 0.45 ms for the two paired gradients of the cfg-5 shard).
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
-    static int sym = -1;
-    if (sym < 0) { const char* e = getenv("REGT_WGRAD_SYM"); sym = e ? atoi(e) : 1; }
     WgradArgs am = a;
-    am.all_csum = sym && a.colsum && a.p_bf16 && a.q_bf16;     // (fp32 kernels: measured no gain, +0.02 ms on the MFMA-bound wgrad3_kernel)
+    am.all_csum = a.colsum && a.p_bf16 && a.q_bf16;     // (fp32 kernels: measured no gain, +0.02 ms on the MFMA-bound wgrad3_kernel)
     return launch_wgrad_impl(am, st);
 }
 static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
@@ -2942,13 +2929,9 @@ static int launch_wgrad_impl(const WgradArgs& a, hipStream_t st) {
             const long ld_max = std::max(a.ldp, std::max(a.ldq, a.Q2 ? a.ldq2 : 0L));
             const long rows_max = a.chunk_tab ? a.M : (long)a.kchunk + 32;
             const bool ring_ok = a.p_bf16 && a.q_bf16 && ring > 0 && (!a.Q2 || a.nin_split % 128 == 0) && 2 * rows_max * ld_max < (1L << 31);
-            // experiment: REGT_WGRAD_OCC = 1 | 2 pads the dynamic LDS so that only that many workgroups share a CU
-            static int occ = -1;
-            if (occ < 0) { const char* e = getenv("REGT_WGRAD_OCC"); occ = e ? atoi(e) : 0; }
-            auto padded = [&](size_t need) { return occ > 0 ? std::max(need, (size_t)(160 * 1024 / occ - 1024)) : need; };
             auto launch_ring = [&](auto kernel, long nblocks, size_t need) -> int {
                 static bool attr_done_r = false;
-                const size_t bytes = padded(need);
+                const size_t bytes = need;
                 if (bytes > 48 * 1024) { if (int rc = set_lds_once(kernel, (int)bytes, &attr_done_r)) return rc; }
                 hipLaunchKernelGGL(kernel, dim3((unsigned)nblocks), dim3(256), bytes, st, a);
                 return REGT_OK;
@@ -3311,8 +3294,7 @@ int launch_small_gemm_multi(SgBatch& b, hipStream_t st) {
         // matrix-sized outputs take the tiled form (split = 0)
         // (sums longer than 256 over few tiles -- d cheb_w1 = sum over the owned regions, K = R C -- stay on the 8-lane form: 16
         // workgroups walking 64 chunks each were slower, 0.25 vs 0.15 ms for the launch; REGT_SG_TILED_MAXK: developer switch)
-        static long tiled_maxk = -1;
-        if (tiled_maxk < 0) { const char* e = getenv("REGT_SG_TILED_MAXK"); tiled_maxk = e ? atol(e) : 256; }
+        constexpr long tiled_maxk = 256;
         if (task.m >= 16 && task.n >= 16 && ksum >= 16 && ksum <= tiled_maxk) {
             task.split = 0;
             blocks += (int)((long)cdiv(task.m, 32) * cdiv(task.n, 32) * task.nbatch);

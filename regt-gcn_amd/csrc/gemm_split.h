@@ -403,17 +403,14 @@ struct SplitCore : FastCore<true, REGION> {
         for (int j = 0; j < 2; ++j) rb[h + 2 * j] = buf_ld4(d.b, d.vb[j], d.sb + 64 * h);
     }
     // run_u's schedule with generated A slots; ONE segment (its B = the weights, [N][K]; its A pointer is not read), K % 32 == 0.
-    // `rot` > 0 walks the k slabs rotated by that many slabs (experiment, REGT_DGRAD1_ROT=1: the tile's own 128 columns last, so
-    // that the epilogue's second read of Z / H~ of those columns might still hit the XCD's L2 -- measured WORSE: the two column
-    // tiles of a row tile then no longer fetch the same slab at the same time and stop sharing their A rows through L2:
-    // 10.3 instead of 7.6 GB fetched per launch, 2.73 instead of 2.65 ms; profiles/r04_gen_pmc.txt).
-    __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g, int rot) {
+    // (walking the k slabs rotated so that the tile's own 128 columns come last was measured WORSE: profiles/r04_gen_pmc.txt)
+    __device__ __forceinline__ void run_u_gen(f32x16 (&acc)[2][2], const AGen& g) {
         static_assert(NP == 0 || NP == 3, "generated A operand: fp32 storage (fp32 MFMA or the exact bf16x3 split)");
         nreg_u = 0;
         const int nslab = S.seg[0].K / GBK;
         if (nslab == 0) return;
         const bool writer = n0 == 0;
-        auto kof = [&](int i) { int q = i + rot; if (q >= nslab) q -= nslab; return q * GBK; };      // k0 of the i-th slab walked
+        auto kof = [&](int i) { return i * GBK; };      // k0 of the i-th slab walked
         __syncthreads();                            // the row table (fill_rowtab) is complete
         const GenRows rows = gen_rows(g);
         GenRegs q;

@@ -30,11 +30,10 @@ __global__ void pack_x_kernel(const float* __restrict__ x, float* __restrict__ x
 }
 
 // The same transposition staged through LDS: a workgroup takes NB whole nodes (NB * F * T floats, contiguous on both sides), reads
-// them with coalesced 16-byte loads, and writes 16-byte pieces of (node, period) rows.  NTL: the snapshot is read exactly once ->
+// them with coalesced 16-byte loads, and writes 16-byte pieces of (node, period) rows.  The snapshot is read exactly once ->
 // non-temporal loads, so that the lines of x do not displace the packed rows (which the aggregation reads next) from the
 // Infinity Cache.  F % 4 == 0, NB * F * T <= PACK_LDS_FLOATS.
 constexpr int PACK_LDS_FLOATS = 4096;
-template <bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void pack_x_lds_kernel(const float* __restrict__ x, float* __restrict__ xp, int N, int F, int T, int NB) {
     __shared__ float4 tile4[PACK_LDS_FLOATS / 4];
     float* tile = reinterpret_cast<float*>(tile4);
@@ -45,13 +44,9 @@ __global__ __launch_bounds__(256) void pack_x_lds_kernel(const float* __restrict
         const float4* src = reinterpret_cast<const float4*>(x + n0 * FT);
         for (int i = threadIdx.x; i < tot4; i += 256) {
             float4 v;
-            if (NTL) {
-                const float* s = reinterpret_cast<const float*>(src + i);
-                v.x = __builtin_nontemporal_load(s); v.y = __builtin_nontemporal_load(s + 1);
-                v.z = __builtin_nontemporal_load(s + 2); v.w = __builtin_nontemporal_load(s + 3);
-            } else {
-                v = src[i];
-            }
+            const float* s = reinterpret_cast<const float*>(src + i);
+            v.x = __builtin_nontemporal_load(s); v.y = __builtin_nontemporal_load(s + 1);
+            v.z = __builtin_nontemporal_load(s + 2); v.w = __builtin_nontemporal_load(s + 3);
             tile4[i] = v;
         }
         __syncthreads();
@@ -60,49 +55,28 @@ __global__ __launch_bounds__(256) void pack_x_lds_kernel(const float* __restrict
             const int n = o / (T * F4), rem = o - n * T * F4;
             const int t = rem / F4, f = (rem - t * F4) * 4;
             const float* b = tile + n * FT + f * T + t;
-            const float4 v = make_float4(b[0], b[T], b[2 * T], b[3 * T]);
-            if (NTS) {
-                float* d = reinterpret_cast<float*>(dst + o);
-                __builtin_nontemporal_store(v.x, d); __builtin_nontemporal_store(v.y, d + 1);
-                __builtin_nontemporal_store(v.z, d + 2); __builtin_nontemporal_store(v.w, d + 3);
-            } else {
-                dst[o] = v;
-            }
+            dst[o] = make_float4(b[0], b[T], b[2 * T], b[3 * T]);      // (ordinary stores: the packed rows are read next)
         }
         __syncthreads();
     }
 }
 
-__global__ void pack_x_nt_kernel(const float* __restrict__ x, float* __restrict__ xp, long N, int F, int T) {
-    const long total = N * F * T;
-    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
-        long n = o / ((long)F * T);
-        int rem = (int)(o - n * F * T);
-        int t = rem / F, f = rem - t * F;
-        xp[o] = __builtin_nontemporal_load(x + n * F * T + (long)f * T + t);
-    }
-}
-
-// REGT_PACK: 0 element-wise (round 1), 1 element-wise with nt loads, 2 LDS-staged, 3 LDS-staged + nt loads (default), 4 = 3 + nt stores
+// LDS-staged with non-temporal loads of the snapshot (round 4: profiles/r04_pack_ab.txt -- the other variants measured there are gone);
+// rows wider than the LDS tile or unaligned pointers take the element-wise kernel
 int launch_pack_x(const float* x, float* xp, int N, int F, int T, hipStream_t st) {
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("REGT_PACK"); variant = e ? atoi(e) : 3; }
     long total = (long)N * F * T;
     const int FT = F * T;
-    if (variant >= 2 && F % 4 == 0 && FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
+    if (F % 4 == 0 && FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
         const int NB = PACK_LDS_FLOATS / FT;
         long blocks = cdiv((long)N, NB);
         if (blocks > 256L * 16) blocks = 256L * 16;
-        if (variant == 2) hipLaunchKernelGGL((pack_x_lds_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
-        else if (variant == 4) hipLaunchKernelGGL((pack_x_lds_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
-        else hipLaunchKernelGGL((pack_x_lds_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
+        hipLaunchKernelGGL(pack_x_lds_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xp, N, F, T, NB);
         REGT_CHECK_LAUNCH();
         return REGT_OK;
     }
     int blocks = cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
-    if (variant == 1) hipLaunchKernelGGL(pack_x_nt_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
-    else hipLaunchKernelGGL(pack_x_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
+    hipLaunchKernelGGL(pack_x_kernel, dim3(blocks), dim3(256), 0, st, x, xp, (long)N, F, T);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -159,10 +133,8 @@ __global__ __launch_bounds__(256) void pack_x_bf16_lds_kernel(const float* __res
 }
 int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_t st) {
     REGT_CHECK_ARG(F % 8 == 0, "pack_x (bf16 rows): F = %d must be a multiple of 8", F);
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("REGT_PACK"); variant = e ? atoi(e) : 3; }
     const int FT = F * T;
-    if (variant >= 2 && FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
+    if (FT <= PACK_LDS_FLOATS && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xp)) & 15) == 0) {
         const int NB = PACK_LDS_FLOATS / FT;
         long blocks = cdiv((long)N, NB);
         if (blocks > 256L * 16) blocks = 256L * 16;
@@ -177,31 +149,22 @@ int launch_pack_x_bf16(const float* x, void* xp, int N, int F, int T, hipStream_
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
-// n8 groups of 8 fp32 -> 8 bf16 (packed rows handed over as fp32 by a caller of regt_forward_packed)
-template <bool NTL>
+// n8 groups of 8 fp32 -> 8 bf16 (packed rows handed over as fp32 by a caller of regt_forward_packed).  Read once: non-temporal loads, so
+// that the fp32 rows do not displace the bf16 rows (read next by the aggregation) from the Infinity Cache.
 __global__ void cvt_rows_bf16_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, long n8) {
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n8; o += (long)gridDim.x * blockDim.x) {
-        if (NTL) {
-            // read once: non-temporal, so that the fp32 rows do not displace the bf16 rows (read next by the aggregation) from the Infinity Cache
-            const float* s = reinterpret_cast<const float*>(src + 2 * o);
-            float a[8];
+        const float* s = reinterpret_cast<const float*>(src + 2 * o);
+        float a[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = __builtin_nontemporal_load(s + i);
-            dst[o] = make_uint4(pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7]));
-        } else {
-            const float4 a = src[2 * o], b = src[2 * o + 1];
-            dst[o] = make_uint4(pk2(a.x, a.y), pk2(a.z, a.w), pk2(b.x, b.y), pk2(b.z, b.w));
-        }
+        for (int i = 0; i < 8; ++i) a[i] = __builtin_nontemporal_load(s + i);
+        dst[o] = make_uint4(pk2(a[0], a[1]), pk2(a[2], a[3]), pk2(a[4], a[5]), pk2(a[6], a[7]));
     }
 }
 int launch_cvt_rows_bf16(const float* src, void* dst, long n, hipStream_t st) {
     REGT_CHECK_ARG(n % 8 == 0, "cvt_rows_bf16: element count must be a multiple of 8");
     int blocks = cdiv(n / 8, 256);
     if (blocks > 16384) blocks = 16384;
-    static int ntl = -1;
-    if (ntl < 0) { const char* e = getenv("REGT_CVT_NT"); ntl = e ? atoi(e) : 1; }
-    if (ntl) hipLaunchKernelGGL(cvt_rows_bf16_kernel<true>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
-    else hipLaunchKernelGGL(cvt_rows_bf16_kernel<false>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
+    hipLaunchKernelGGL(cvt_rows_bf16_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const float4*>(src), reinterpret_cast<uint4*>(dst), n / 8);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -383,13 +346,12 @@ __global__ __launch_bounds__(256) void spmm_panel_kernel(const int* __restrict__
 // The regional Laplacian rows are (almost) a subset of the full-graph rows: the same neighbour row
 // x[col] feeds both A_hat x and L~ x.  With a merged CSR that carries two weights per entry, one gather
 // serves both outputs -- half the gather volume of the stacked operator.  Same XCD/panel schedule as above.
-template <int PL, int IDX, bool NTS, bool CNT = false>   // PL lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two);
-                                        // IDX (<= PL) CSR entries fetched per index load; NTS: streaming output stores;
-                                        // CNT: non-temporal loads of the CSR entries (A/B: REGT_SPMM_CSRNT)
+template <int PL, int IDX>              // PL lanes per row = panel width in float4 (8: one 128-B line per neighbour, 16: two);
+                                        // IDX (<= PL) CSR entries fetched per index load
 __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restrict__ rowptr, const int* __restrict__ col,
                                                               const float* __restrict__ val_a, const float* __restrict__ val_l,
                                                               const float* __restrict__ X, float* __restrict__ YA,
-                                                              float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb, int ldx4) {
+                                                              float* __restrict__ YL, int nnodes, int W4, int npanels, int nrb) {
     static_assert(IDX % 8 == 0 && IDX <= PL, "index chunk is a multiple of the 8-gather round and fits the lane group");
     constexpr int ROWS = 256 / PL;
     const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3;
@@ -409,10 +371,7 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
         const int n = end - base < IDX ? end - base : IDX;
         int myc = 0;
         float mya = 0.f, myl = 0.f;
-        if (gl < n) {
-            if (CNT) { myc = __builtin_nontemporal_load(col + base + gl); mya = __builtin_nontemporal_load(val_a + base + gl); myl = __builtin_nontemporal_load(val_l + base + gl); }
-            else { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
-        }
+        if (gl < n) { myc = col[base + gl]; mya = val_a[base + gl]; myl = val_l[base + gl]; }
 #pragma unroll
         for (int r = 0; r < IDX / 8; ++r) {
             if (r * 8 < n) {
@@ -424,7 +383,7 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
                     const int c = __shfl(myc, r * 8 + e, PL);
                     va[e] = __shfl(mya, r * 8 + e, PL);
                     vl[e] = __shfl(myl, r * 8 + e, PL);
-                    x[e] = r * 8 + e < n ? X4[(long)c * ldx4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    x[e] = r * 8 + e < n ? X4[(long)c * W4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -438,7 +397,7 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
     }
     float4* pa = reinterpret_cast<float4*>(YA) + row * W4 + panel * PL + gl;
     float4* pl = reinterpret_cast<float4*>(YL) + row * W4 + panel * PL + gl;
-    if (NTS) {
+    {
         // the outputs are not read again by this kernel: streaming stores keep them from evicting the XCD's slice of X
         // from its L2 (cfg-3, X resident in the Infinity Cache: 186 -> 149 us, L2 hits 64 -> 70 %; inside a training
         // step, where X comes from HBM, 174 -> 167 us)
@@ -446,9 +405,6 @@ __global__ __launch_bounds__(256) void spmm_dual_panel_kernel(const int* __restr
         __builtin_nontemporal_store(aa.z, &pa->z); __builtin_nontemporal_store(aa.w, &pa->w);
         __builtin_nontemporal_store(al.x, &pl->x); __builtin_nontemporal_store(al.y, &pl->y);
         __builtin_nontemporal_store(al.z, &pl->z); __builtin_nontemporal_store(al.w, &pl->w);
-    } else {
-        *pa = aa;
-        *pl = al;
     }
 }
 
@@ -656,6 +612,13 @@ static int launch_spmm_rows(const int* rowptr, const int* col, const float* val_
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
+// 256-byte column panels (two cache lines per neighbour: half the passes over the CSR) while an XCD's slice of X (node chunk x 256 B)
+// stays around its 4 MiB L2, else 128-byte ones; REGT_SPMM_PL=8|16 forces one (tools/spmm_pmc.sh)
+static bool panel_wide(int nnodes) {
+    static int pl_env = -1;
+    if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
+    return pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX;
+}
 // REGT_SPMM_ROWS / regt_set_option("spmm_rows"): 1 = row-block kernel where eligible, 0 (default) = panel kernels
 static int g_rows_opt = -1;
 static bool rows_wanted() {
@@ -677,9 +640,7 @@ int launch_spmm_dual_bf16(const int* rowptr, const int* col, const float* val_a,
                           int nnodes, int x_rows, int W, hipStream_t st) {
     REGT_CHECK_ARG(nnodes > 0 && W > 0 && W % 64 == 0, "spmm_dual (bf16 rows): width %d must be a multiple of 64 elements", W);
     const long rowbytes = 2L * W;
-    static int pl_env = -1;
-    if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && rowbytes % 256 == 0;
+    const bool wide = panel_wide(nnodes) && rowbytes % 256 == 0;
     const int PL = wide ? 16 : 8;
     REGT_CHECK_ARG(x_rows * rowbytes < (1L << 32) - 4096, "spmm_dual (bf16 rows): X larger than 4 GB");
     if (rows_wanted() && (256 / PL) * rows_rpg(nnodes, PL, true) <= 256)
@@ -728,42 +689,21 @@ int launch_spmm_dual_x(const int* rowptr, const int* col, const float* val_a, co
         return REGT_OK;
     }
     {
-        static int pl_env0 = -1;
-        if (pl_env0 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env0 = e ? atoi(e) : 0; }
-        const bool wide0 = (pl_env0 ? pl_env0 == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;
+        const bool wide0 = panel_wide(nnodes) && W4 % 16 == 0;
         const int PL0 = wide0 ? 16 : 8;
         if (rows_ok(nnodes, x_rows, 4L * W, PL0))
             return launch_spmm_rows<true, false>(rowptr, col, val_a, val_l, X, YA, YL, nnodes, x_rows, 4 * W, PL0, st);
     }
-    static int pl_env = -1;
-    if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-    // two cache lines per neighbour (halves the CSR re-reads) while the XCD's slice of X (chunk x 256 B) stays
-    // around the 4 MiB L2: measured 182 vs 197 us at cfg-3 (3.2 MB slice)
-    const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
+    const bool wide = panel_wide(nnodes) && W4 % 16 == 0;     // (a forced 256-byte panel still needs whole panels)
     const int PL = wide ? 16 : 8;
     const int npanels = W4 / PL;
     const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);
     const long grid = 8L * npanels * nrb;
     REGT_CHECK_ARG(grid < (1L << 31), "spmm_dual: grid too large");
-    static int nt_env = -1, idx_env = -1, cnt_env = -1, xld_env = -1;
-    if (nt_env < 0) { const char* e = getenv("REGT_SPMM_NT"); nt_env = e ? atoi(e) : 1; }
-    if (idx_env < 0) { const char* e = getenv("REGT_SPMM_IDX"); idx_env = e ? atoi(e) : 16; }
-    if (cnt_env < 0) { const char* e = getenv("REGT_SPMM_CSRNT"); cnt_env = e ? atoi(e) : 0; }
-    if (xld_env < 0) { const char* e = getenv("REGT_SPMM_XLD"); xld_env = e ? atoi(e) : 0; }   // experiment: row stride of X in floats
-    const int ldx4 = xld_env > 0 ? xld_env / 4 : W4;
-#define REGT_DUAL(PLL, IDXX, NTT, ...)                                                                                              \
-    hipLaunchKernelGGL((spmm_dual_panel_kernel<PLL, IDXX, NTT, ##__VA_ARGS__>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, \
-                       X, YA, YL, nnodes, W4, npanels, nrb, ldx4)
-    if (wide) {
-        if (nt_env == 0) REGT_DUAL(16, 8, false);
-        else if (idx_env == 8) REGT_DUAL(16, 8, true);
-        else if (cnt_env) REGT_DUAL(16, 16, true, true);
-        else REGT_DUAL(16, 16, true);
-    } else {
-        if (nt_env == 0) REGT_DUAL(8, 8, false);
-        else REGT_DUAL(8, 8, true);
-    }
-#undef REGT_DUAL
+    // (streaming output stores, 16-entry index chunks: the variants measured against them -- ordinary stores, 8-entry chunks,
+    // non-temporal CSR loads, a padded X stride: profiles/r03_spmm_pmc_variants.txt, r04_spmm_ab.txt -- are gone)
+    if (wide) hipLaunchKernelGGL((spmm_dual_panel_kernel<16, 16>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL, nnodes, W4, npanels, nrb);
+    else hipLaunchKernelGGL((spmm_dual_panel_kernel<8, 8>), dim3((unsigned)grid), dim3(256), 0, st, rowptr, col, val_a, val_l, X, YA, YL, nnodes, W4, npanels, nrb);
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }
@@ -791,16 +731,12 @@ int launch_spmm_csr(const int* rowptr, const int* col, const float* val, const f
     if (W4 % 8 == 0 && (long)nrows_x * W * 4 > (24L << 20) && nrows / nstack >= 4096) {
         const int nnodes = nrows / nstack;
         if (nstack == 1) {      // one operator: the row-block kernel (CSR entries in LDS, the workgroup walks all panels)
-            static int pl_env1 = -1;
-            if (pl_env1 < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env1 = e ? atoi(e) : 0; }
-            const bool wide1 = (pl_env1 ? pl_env1 == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;
+            const bool wide1 = panel_wide(nnodes) && W4 % 16 == 0;
             if (rows_ok(nnodes, nrows_x, 4L * W, wide1 ? 16 : 8))
                 return launch_spmm_rows<false, false>(rowptr, col, val, nullptr, X, Y, nullptr, nnodes, nrows_x, 4 * W, wide1 ? 16 : 8, st);
         }
         // 256-byte panels (half the passes over the CSR) while an XCD's slice of X (chunk x 256 B) stays around its 4 MiB L2
-        static int pl_env = -1;
-        if (pl_env < 0) { const char* e = getenv("REGT_SPMM_PL"); pl_env = e ? atoi(e) : 0; }
-        const bool wide = (pl_env ? pl_env == 16 : (long)cdiv(nnodes, 8) * 256 <= SP_WIDE_SLICE_MAX) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
+        const bool wide = panel_wide(nnodes) && W4 % 16 == 0;   // a forced 256-byte panel still needs whole panels
         const int PL = wide ? 16 : 8;
         const int npanels = W4 / PL;
         const int nrb = cdiv(cdiv(nnodes, 8), 256 / PL);

@@ -332,7 +332,9 @@ class FusedTrainStep:
         N, F, T = graph.num_nodes, num_features, periods
         Cdim = tens["tgnn.conv.bias"].numel()
         O, H1 = tens["linear2.weight"].shape[0], tens["linear1.weight"].shape[0]
-        self.dims = _lib.Dims(N, T, F, Cdim, graph.num_regions, O, H1, 1 if self.regional else 0, float(slope), arith, 0)
+        # (the model's per-call switches -- DIMS_NO_BF16_ROWS / _NO_FUSED_BWD / _NO_SIDE_STREAM -- apply here as under autograd)
+        self.dims = _lib.Dims(N, T, F, Cdim, graph.num_regions, O, H1, 1 if self.regional else 0, float(slope), arith,
+                              int(getattr(model, "call_flags", 0)))
         self.gs = _graph_struct(graph, T)
         self.wsb = lib.regt_workspace_bytes(C.byref(self.dims), self.gs.n_chunks, self.gs.overlap)
         if self.wsb == 0:

@@ -794,6 +794,24 @@ def test_call_flags_are_per_call_switches():
         assert len(per_call) == len(process_wide) and all(torch.equal(a_, b_) for a_, b_ in zip(per_call, process_wide)), opt
     assert lib.regt_set_option(b"xbf", 1) == 1 and lib.regt_set_option(b"fused_bwd", 1) == 1      # process defaults untouched
 
+    # functional.FusedTrainStep (train.py --fused_step) passes the model's switches on as well: with NO_BF16_ROWS the accumulated
+    # gradients are those of the autograd path under the same flag, bit for bit
+    def fused_step(flags):
+        m = R.RegionalTemporalGCN(node_features=f, num_nodes=n, periods=t, output_dim=o, num_regions=regions)
+        m.load_state_dict(p, strict=True)
+        m.arithmetic, m.call_flags = "bf16", flags
+        m = m.cuda()
+        graph = m.prepare_graph(ei.cuda(), [i.cuda() for i in ri], [a.cuda() for a in rw])
+        st = R.functional.FusedTrainStep(m, graph, f, t)
+        assert st.dims.flags == flags
+        st(x.cuda(), y)
+        torch.cuda.synchronize()
+        return [q.grad.detach().clone() for q in st.params]
+
+    g_flag, g_plain = fused_step(_lib.DIMS_NO_BF16_ROWS), fused_step(0)
+    assert all(bool(torch.isfinite(a_).all()) for a_ in g_flag)
+    assert not all(torch.equal(a_, b_) for a_, b_ in zip(g_flag, g_plain))      # (x is rounded at another point: another path did run)
+
 
 def test_big_tile_shapes_take_the_round4_kernels():
     """Guard against a silent fallback: at a shape with >= 128 GEMM tiles the fp32 backward runs the generated-operand candidate data

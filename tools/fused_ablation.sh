@@ -7,8 +7,6 @@
 out=gpurun_out/fused_fwd_ablation.txt; : > $out
 run() { echo "== $1" >> $out; shift; env "$@" python tools/mode_bench.py cfg5shard 2 10 2>/dev/null | grep -E "mode 2|fused_forward" >> $out; }
 run "baseline" A=1
-run "zero-record store descriptors (REGT_FUSED_DBG=1)" REGT_FUSED_DBG=1
-run "zero-record weight descriptors (REGT_FUSED_DBG=2)" REGT_FUSED_DBG=2
 for v in 1 2 4 8 16 32 48 63; do [ -d regt-gcn_amd/lib_abl$v ] && run "REGT_FUSED_ABL=$v" REGT_LIB_DIR=regt-gcn_amd/lib_abl$v; done
 run "baseline again" A=1
 cat $out

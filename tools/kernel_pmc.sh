@@ -1,8 +1,9 @@
 #!/bin/bash
 # PMC passes (HBM bytes, SQ activity) over tools/mode_bench.py for one kernel-name substring (GPU box, repo root):
 #   tools/kernel_pmc.sh <tag> <kernel substring> [workload] [mode] [ENV=v ...]
-tag=$1; pat=$2; wl=${3:-cfg3}; mode=${4:-0}; shift 4 2>/dev/null
-for kv in "$@"; do export "$kv"; done
+tag=$1; pat=$2; wl=${3:-cfg3}; mode=${4:-0}
+shift $(( $# < 4 ? $# : 4 ))
+for kv in "$@"; do [[ "$kv" =~ ^[A-Za-z_][A-Za-z0-9_]*= ]] && export "$kv"; done
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out
 pass() {

@@ -7,8 +7,7 @@ nodes, edges, regions, W = 100_000, 1_000_000, 8, 384
 g = R.data.synthetic_regional_graph(nodes, edges, regions, seed=42)
 dev = torch.device("cuda")
 pg = R.prepare_graph(g.edge_index.to(dev), None, [t.to(dev) for t in g.region_index], [t.to(dev) for t in g.region_attr], nodes)
-XLD = int(os.environ.get("REGT_SPMM_XLD", "0")) or W          # experiment: row stride of X in floats (L2 set usage of a strided slice)
-x = torch.rand(nodes, XLD, device=dev)
+x = torch.rand(nodes, W, device=dev)
 def t(fn, n=30):
     for _ in range(5): fn()
     torch.cuda.synchronize()
