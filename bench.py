@@ -49,8 +49,8 @@ PEAK_HBM_GBS = 8000.0             # HBM3E spec peak (6.3 TB/s is the measured ac
 # HBM bytes per launch come from rocprofv3 PMC passes of this same command (tools/bench_pmc.sh -> tools/pmc_summary.py):
 # 2 x FETCH_SIZE (gfx950 reports half the bytes of 16-B/lane streaming reads -- MI355X_MICROARCH.md, HBM section;
 # calibrated on cell_bwd, whose 3.7 GB of float4 reads show as 2.08e6 KB) + WRITE_SIZE, both in KB in the summary.
-PMC_SUMMARIES = {("cfg3", 0): "profiles/r04_cfg3_pmc_hbm_summary.txt",
-                 ("cfg5shard", 2): "profiles/r04_cfg5shard_pmc_hbm_summary.txt"}
+PMC_SUMMARIES = {("cfg3", 0): "profiles/r05_cfg3_pmc_hbm_summary.txt",
+                 ("cfg5shard", 2): "profiles/r05_cfg5shard_pmc_hbm_summary.txt"}
 
 WORKLOADS = {
     # per-GPU shape: nodes, edges, regions, F, T, O; GEMM arithmetic (regt_set_gemm_mode) and the dtype it computes in
@@ -402,7 +402,7 @@ def stage_kernel(stage, mode):
             pats.insert(0, f"gemm_flat_split8_kernel<regt::{epi}8F, false>")
         return pats
     if stage == "fused_forward":
-        return ["fused_fwd_kernel"]
+        return ["fused_fwd_rows_kernel", "fused_fwd_kernel"]
     if stage == "fused_backward":
         return ["fused_bwd_kernel"]
     if stage == "gemm_candidate":

@@ -2,7 +2,7 @@
 # rocprofv3 passes over bench.py (GPU box, repo root): kernel-trace stats + three PMC passes (counters in their own runs).
 #   tools/bench_pmc.sh <tag> [bench.py args...]      e.g.  tools/bench_pmc.sh cfg3 --workload cfg3
 # Writes gpurun_out/<tag>_kernel_stats.csv, <tag>_pmc_hbm_summary.txt, <tag>_pmc_sq_summary.txt, <tag>_bench.json;
-# copy the ones to be judged into profiles/ (bench.py reads profiles/r04_<workload>_pmc_hbm_summary.txt for `traffic`).
+# copy the ones to be judged into profiles/ (bench.py reads profiles/r05_<workload>_pmc_hbm_summary.txt for `traffic`).
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 mkdir -p gpurun_out
