@@ -228,7 +228,8 @@ bool xbf_ok(const regt_dims& d, const regt_graph& g, bool h_ext, int x_rows, boo
 }
 // The row-owning fused forward (fused_rows.hip) instead of the 64-row one: C = 256, F = 32 / 64, T <= 16 and region ids sorted by node.
 // The three-launch path of the same arithmetic follows with its per-node sums (CandArgs::node_sum_rows), whichever forward runs:
-// the forms stay bit-identical (tests/test_gpu_fused.py).  regt_set_option("fused_rows", 0): the 64-row kernel everywhere.
+// the forms stay bit-identical (tests/test_gpu_fused.py).  regt_set_option("fused_rows", 0): the 64-row kernel everywhere; 2: the
+// row-owning kernel as two workgroups of four waves per CU (a test variant, see kernels.h).
 static int g_opt_fused_rows = 1;
 bool fused_rows_form(const regt_dims& d, const regt_graph& g) {
     return g_opt_fused_rows && fused_forward_rows_ok(d.C, d.F, d.T) && d.regional && !g.overlap && (d.R == 1 || g.region_sorted);
@@ -552,7 +553,7 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
             a.M = M; a.T = T; a.slope = d.lrelu_slope; a.act_lrelu = 1; a.tile_ctr = L.tile_ctr;
             PROF("fused_forward", st);
             TRY(launch_zero_f32(hidden, (long)N * C, st));
-            if (fused_rows_form(d, g)) TRY(launch_fused_forward_rows(a, C, F, st));
+            if (fused_rows_form(d, g)) TRY(launch_fused_forward_rows(a, C, F, g_opt_fused_rows == 2 ? 4 : 8, st));
             else TRY(launch_fused_forward(a, C, F, st));
         }
         return head_forward(d, p, hidden, L.y1, pred, st);
@@ -1223,7 +1224,7 @@ const char* regt_last_error(void) { return g_err; }
 int32_t regt_set_option(const char* name, int32_t value) {
     REGT_CHECK_ARG(name != nullptr, "regt_set_option: name is NULL");
     if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
-    if (!strcmp(name, "fused_rows")) { const int prev = g_opt_fused_rows; g_opt_fused_rows = value ? 1 : 0; return prev; }
+    if (!strcmp(name, "fused_rows")) { const int prev = g_opt_fused_rows; g_opt_fused_rows = value == 2 ? 2 : (value ? 1 : 0); return prev; }
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);

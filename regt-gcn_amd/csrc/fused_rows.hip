@@ -27,21 +27,23 @@ namespace regt {
 
 namespace {
 
-constexpr int FR_ROWS = 128;             // rows of a tile: 8 waves x 16
-constexpr int FR_SLOTS = 16;             // ring slots (128 KB: a request takes ~3 k cycles to land under load, and what is in flight
-                                         //   sets the rate -- with 8 slots the K loops waited for the ring, matrix work or not)
-constexpr int FR_AHEAD = 15;             // slices requested ahead of the one being consumed
+// NW waves x 16 rows make a tile.  NW = 8: one workgroup per CU, 16 ring slots (128 KB: a request takes ~3 k cycles to land under load,
+// and what is in flight sets the rate -- with 8 slots the K loops waited for the ring, matrix work or not).  NW = 4: two workgroups
+// per CU with a ring of 8 slots each -- twice the L2 -> LDS weight traffic per row, but one workgroup's epilogues (stores, gate
+// math) run under the other's K loops.
 constexpr int FR_SLICE_B = 8192;         // 32 k x 128 columns of bf16 in MFMA fragment order (eight 1 KB blocks of launch_cvt_bf16_frag)
 constexpr int FR_IMG_B = 2048;           // a wave's epilogue image: 16 rows x 32 columns fp32
 constexpr int FR_C = 256;
 
 // (biases and images first: their addresses then fit the 16-bit offset field of the LDS instructions -- behind the 64 KB ring every
 // one of the 32 bias reads of a tile needed an address register of its own, which hipcc spilled)
+template <int NW>
 struct FusedRowsLds {
+    static constexpr int SLOTS = NW == 8 ? 16 : 8;                // ring slots; SLOTS - 1 slices are requested ahead of the one being consumed
     static constexpr int BIAS_OFF = 0;
     static constexpr int IMG_OFF = BIAS_OFF + 4 * FR_C * 4;
-    static constexpr int RING_OFF = IMG_OFF + 8 * FR_IMG_B;
-    static constexpr int NEXT_OFF = RING_OFF + FR_SLOTS * FR_SLICE_B;   // the workgroup's next tile (drawn from the tile counter)
+    static constexpr int RING_OFF = IMG_OFF + NW * FR_IMG_B;
+    static constexpr int NEXT_OFF = RING_OFF + SLOTS * FR_SLICE_B;   // the workgroup's next tile (drawn from the tile counter)
     static constexpr int BYTES = NEXT_OFF + 16;
 };
 
@@ -60,11 +62,14 @@ __device__ __forceinline__ constexpr int fr_par(int r) { return ((r >> 1) & 3) |
 // (region ids sorted by node: a tile's regions are a range)
 struct FrTileInfo { int rg_first, nreg; };
 
-template <int F>
-__global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) {
+template <int F, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) {
     constexpr int C = FR_C, KF = F / 32;                         // k blocks (32 k) of a K = F operand
     static_assert(F == 32 || F == 64, "row widths");
-    using L = FusedRowsLds;
+    static_assert(NW == 8 || NW == 4, "waves of a workgroup");
+    using L = FusedRowsLds<NW>;
+    constexpr int FR_ROWS = 16 * NW, FR_SLOTS = L::SLOTS, FR_AHEAD = FR_SLOTS - 1;
+    constexpr int RPW = 8 / NW;                                  // LDS-DMA requests of a wave per slice (1 KB each)
     extern __shared__ __attribute__((aligned(16))) char flds[];
     float* biasl = reinterpret_cast<float*>(flds + L::BIAS_OFF);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
@@ -98,6 +103,7 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     // Wave v copies block (row block nb + v / 2, 16-k block 2 kb + v % 2) of the matrix: 1 KB, contiguous, lane-linear.
     constexpr int S_TILE = 4 * KF + 6 * (8 + KF);
     const int dma_voff = lane * 16;
+    // (NW = 4: the wave also copies block v + 4 -- row block + 2 of the same 16-k block)
     unsigned voff_c = (unsigned)(((v >> 1) * (C / 16) + (v & 1)) * 1024), voff_f = (unsigned)(((v >> 1) * (F / 16) + (v & 1)) * 1024);
     unsigned p_slot = 0;                                         // ring slot of the next slice to be requested
     // request slice s (0 <= s < S_TILE) of a tile whose first region is rg
@@ -123,6 +129,10 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         // (inline asm: hipcc drains the builtin form -- vmcnt(0) in front of every LDS read; the waits for these requests are
         // written by hand in `consume`.  M0 = LDS base of the wave's 1 KB, lane l lands at + 16 l)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(dma_voff), "s"(src) : "memory");
+        if (RPW == 2) {
+            const char* src2 = src + 2 * k16 * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v + 4096u), "v"(dma_voff), "s"(src2) : "memory");
+        }
         p_slot = (p_slot + 1) & (FR_SLOTS - 1);
     };
     // ---- the consumer side of the ring ------------------------------------------------------------------------------------------------
@@ -152,11 +162,13 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         if (t == g0 + 6 * gl - 1) return 4 + 3 * KF + 1;                                      // ... and the next tile's rows
         return 0;
     };
-    // ... issued between the request for slice s + 1 (at step s + 1 - FR_AHEAD) and step s
+    // ... issued between the request for slice s + 2 (early in step s + 3 - FR_AHEAD, together with the one for s + 3) and the barrier
+    // of the even step s: the epilogues behind the slices s + 3 - FR_AHEAD .. s - 1.  (An epilogue behind an earlier slice is OLDER
+    // than that request: counting it would let the request itself be one of the operations the wait leaves outstanding.)
     auto vm_after = [&](int s) {
         int n = 0;
 #pragma unroll
-        for (int t = s - (FR_AHEAD - 1); t < s; ++t) n += vm_epi(t < 0 ? t + S_TILE : t);
+        for (int t = s - (FR_AHEAD - 3); t < s; ++t) n += vm_epi(t < 0 ? t + S_TILE : t);
         return n;
     };
     auto wait_landed = [&](int n) {                              // (n is a constant at every call site: the switch folds)
@@ -168,9 +180,9 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
 #endif
         switch (n) {
 #define W_(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")\n\ts_barrier" ::: "memory"); break;
-            W_(11) W_(12) W_(13) W_(14) W_(15) W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31) W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45)
+            W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16) W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31) W_(32) W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47) W_(48) W_(49) W_(50) W_(51) W_(52) W_(53) W_(54) W_(55) W_(56) W_(57) W_(58) W_(59) W_(60) W_(61) W_(62) W_(63)
 #undef W_
-            default: asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
         }
     };
     bf16x8 bq0[4], bq1[4], bq2[4];                               // (three named arrays, chosen by if-chains that fold at every call site: a
@@ -211,10 +223,10 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         if ((s & 1) == 0) {
             if (s + FR_AHEAD < S_TILE) {
                 // (the workgroup's first tile has no epilogue behind it: counting one would make the wait too weak)
-                if (first_tile && vm_after(s) > 0 && s < FR_AHEAD) wait_landed(FR_AHEAD - 4);
-                else wait_landed(FR_AHEAD - 4 + vm_after(s));
+                if (first_tile && vm_after(s) > 0 && s < FR_AHEAD) wait_landed(RPW * (FR_AHEAD - 4));
+                else wait_landed(RPW * (FR_AHEAD - 4) + vm_after(s));
             } else if (has_next) {
-                wait_landed(FR_AHEAD - 4 + vm_after(s));
+                wait_landed(RPW * (FR_AHEAD - 4) + vm_after(s));
             } else {
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // (the workgroup's last tile: fewer requests are outstanding)
             }
@@ -227,17 +239,17 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
             if (se + FR_AHEAD < S_TILE) { request(se + FR_AHEAD - 1, rg_cur); request(se + FR_AHEAD, rg_cur); }
             else if (has_next) { request(se + FR_AHEAD - 1 - S_TILE, rg_nxt); request(se + FR_AHEAD - S_TILE, rg_nxt); }
         };
-        if ((s & 1) == 0 && v < 4) issue_pair(s);
+        if ((s & 1) == 0 && v < NW / 2) issue_pair(s);
         const unsigned nslot = (c_slot + 1) & (FR_SLOTS - 1);
         if (s == 0) { read_half(0, c_slot, 0); read_half(1, c_slot, 1); }
         if (s + 1 < S_TILE) read_half((2 * s + 2) % 3, nslot, 0);
         mfma_half((2 * s) % 3, acc, 0, af);
-        if ((s & 1) == 0 && v >= 4) issue_pair(s);
+        if ((s & 1) == 0 && v >= NW / 2) issue_pair(s);
         if (s + 1 < S_TILE) read_half((2 * s + 3) % 3, nslot, 1);
         mfma_half((2 * s + 1) % 3, acc, 1, af);
         c_slot = nslot;
     };
-    static_assert(FR_AHEAD == 15 && FR_SLOTS == 16 && S_TILE % 2 == 0 && S_TILE > FR_AHEAD, "the hand-written vmcnt(11) and the slot arithmetic assume fifteen requests ahead in sixteen slots, slices in pairs");
+    static_assert(FR_AHEAD == FR_SLOTS - 1 && (FR_SLOTS & (FR_SLOTS - 1)) == 0 && FR_AHEAD >= 7 && S_TILE % 2 == 0 && S_TILE > FR_AHEAD, "the waits and the slot arithmetic assume SLOTS - 1 requests ahead in a power-of-two ring, slices in pairs");
 
     // ---- epilogue geometry: accumulator pieces of 16 rows x 32 columns through the wave's image ------------------------------------
     // accumulator lane (c = l & 15, g): rows 4 g + i (i = register), column c of its 16-column block; epilogue lane (r = l & 15, g):
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
         for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
 
-    for (int i = tid; i < 4 * C; i += 512) biasl[i] = i < C ? a.bprime[i] : (i < 3 * C ? a.czr[i - C] : a.ch[i - 3 * C]);
+    for (int i = tid; i < 4 * C; i += 64 * NW) biasl[i] = i < C ? a.bprime[i] : (i < 3 * C ? a.czr[i - C] : a.ch[i - 3 * C]);
     __syncthreads();                                            // the biases are in LDS
 
     // ---- what a tile needs from global memory, requested one tile ahead: the wave's rows of x, L~ x, A_hat x as A fragments (lane
@@ -315,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void fused_fwd_rows_kernel(FusedFwdArgs a) 
     for (int s = 0; s < FR_AHEAD - 1; ++s) request(s, info.rg_first);
     // (the first tile's first wait counts operations that a steady-state tile has behind its requests -- here they are in front:
     // make sure slices 0, 1 and 2 have landed before the loop)
-    asm volatile("s_waitcnt vmcnt(11)\n\ts_barrier" ::: "memory");
+    wait_landed(RPW * (FR_AHEAD - 4));
 
 #pragma unroll 1
     while (tile < tiles) {
@@ -530,7 +542,7 @@ int fused_cus();
 
 bool fused_forward_rows_ok(int C, int F, int T) { return C == FR_C && (F == 64 || F == 32) && T <= 16; }
 
-int launch_fused_forward_rows(const FusedFwdArgs& a_, int C, int F, hipStream_t st) {
+int launch_fused_forward_rows(const FusedFwdArgs& a_, int C, int F, int waves, hipStream_t st) {
     REGT_CHECK_ARG(a_.M > 0 && a_.T > 0, "fused forward: empty problem");
     REGT_CHECK_ARG(fused_forward_rows_ok(C, F, a_.T), "fused forward (row form): built for C = 256, F = 32 or 64, T <= 16 (got C = %d, F = %d, T = %d)", C, F, a_.T);
     FusedFwdArgs a = a_;
@@ -538,7 +550,8 @@ int launch_fused_forward_rows(const FusedFwdArgs& a_, int C, int F, hipStream_t 
     a.nodes = a.M / a.T;
     a.pmask = 0;
     for (int rr = 0; rr < 64; rr += a.T) a.pmask |= 1ull << rr;
-    const long tiles = (a.M + FR_ROWS - 1) / FR_ROWS;
+    const int nw = waves == 4 ? 4 : 8;
+    const long tiles = (a.M + 16 * nw - 1) / (16 * nw);
     REGT_CHECK_ARG(a.M < (1L << 31), "fused forward: too many rows");
     a.trace = fused_trace_buffer(1, tiles);
     {   // the weight blocks live in one workspace buffer (api.hip wb_ptrs): one base + 32-bit offsets
@@ -553,19 +566,25 @@ int launch_fused_forward_rows(const FusedFwdArgs& a_, int C, int F, hipStream_t 
         }
         a.wbase = base;
     }
-    using L = FusedRowsLds;
     static bool attr_done = false;
     if (!attr_done) {
-        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
-        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES));
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedRowsLds<8>::BYTES));
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<32, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedRowsLds<8>::BYTES));
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedRowsLds<4>::BYTES));
+        REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fused_fwd_rows_kernel<32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, FusedRowsLds<4>::BYTES));
         attr_done = true;
     }
-    // persistent: one workgroup of eight waves per CU
-    const long slots = fused_cus();
+    // persistent: 8 waves per CU (one workgroup of eight or two of four)
+    const long slots = (long)fused_cus() * (8 / nw);
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     if (a.tile_ctr) REGT_CHECK_HIP(hipMemsetAsync(a.tile_ctr, 0, sizeof(unsigned), st));
-    if (F == 64) hipLaunchKernelGGL((fused_fwd_rows_kernel<64>), dim3(grid), dim3(512), L::BYTES, st, a);
-    else hipLaunchKernelGGL((fused_fwd_rows_kernel<32>), dim3(grid), dim3(512), L::BYTES, st, a);
+    if (nw == 8) {
+        if (F == 64) hipLaunchKernelGGL((fused_fwd_rows_kernel<64, 8>), dim3(grid), dim3(512), FusedRowsLds<8>::BYTES, st, a);
+        else hipLaunchKernelGGL((fused_fwd_rows_kernel<32, 8>), dim3(grid), dim3(512), FusedRowsLds<8>::BYTES, st, a);
+    } else {
+        if (F == 64) hipLaunchKernelGGL((fused_fwd_rows_kernel<64, 4>), dim3(grid), dim3(256), FusedRowsLds<4>::BYTES, st, a);
+        else hipLaunchKernelGGL((fused_fwd_rows_kernel<32, 4>), dim3(grid), dim3(256), FusedRowsLds<4>::BYTES, st, a);
+    }
     REGT_CHECK_LAUNCH();
     return REGT_OK;
 }

@@ -275,8 +275,10 @@ struct FusedFwdArgs {
 long fused_trace_fetch(long* out, long capacity);
 int launch_fused_forward(const FusedFwdArgs& a, int C, int F, hipStream_t st);
 bool fused_forward_ok(int C, int F);
-// the row-owning form (fused_rows.hip): a wave owns 16 whole rows, weights stream through LDS; needs region ids sorted by node
-int launch_fused_forward_rows(const FusedFwdArgs& a, int C, int F, hipStream_t st);
+// the row-owning form (fused_rows.hip): a wave owns 16 whole rows, weights stream through LDS; needs region ids sorted by node.
+// waves = 8: one workgroup of eight waves per CU (the product form); 4: two workgroups of four with half the ring each (slower --
+// twice the weight traffic -- kept because its short ring is the harder test of the hand-counted waits)
+int launch_fused_forward_rows(const FusedFwdArgs& a, int C, int F, int waves, hipStream_t st);
 bool fused_forward_rows_ok(int C, int F, int T);
 
 // ---- fused data gradients of the cell for the bf16 arithmetic (fused.hip): cell_bwd + dgrad_candidate + dgrad_gates in one kernel

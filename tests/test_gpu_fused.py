@@ -30,6 +30,7 @@ def bf16_mode():
     lib.regt_set_gemm_mode(prev)
     lib.regt_set_option(b"xbf", 1)
     lib.regt_set_option(b"fused_bwd", 1)
+    lib.regt_set_option(b"fused_rows", 1)
     lib.regt_set_option(b"spmm_rows", 0)
     lib.regt_set_option(b"wgrad_ring", 6)
     lib.regt_set_option(b"wgrad_tile", DEFAULT_WGRAD_TILE)
@@ -94,10 +95,11 @@ def test_row_block_kernel_equals_panel_kernel_bit_for_bit(n, e, regions, w):
     assert torch.equal(a1, a0) and torch.equal(l1, l0)
 
 
-def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1, hidden=256):
+def _run(R, n, e, regions, f, t, o, xbf, seed=0, fused_bwd=1, hidden=256, fused_rows=1):
     lib = R.load_library()
     lib.regt_set_option(b"xbf", xbf)
     lib.regt_set_option(b"fused_bwd", fused_bwd)
+    lib.regt_set_option(b"fused_rows", fused_rows)
     ei, ri, rw, x = _synthetic(n, e, regions, f, t, seed=n + seed)
     x = bf16_round(x)
     y = torch.rand(n, o, generator=torch.Generator().manual_seed(1))
@@ -134,6 +136,24 @@ def test_fused_forward_equals_three_launch_path_bit_for_bit(bf16_mode, n, e, reg
         bad = {k: v for k, v in worst.items() if v != 0.0}
         assert not bad, bad
     assert float(h1.abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+@pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES[:3] + [(1500, 15000, 8, 32, 12, 1), (30000, 250000, 8, 64, 12, 1)])
+def test_row_owning_forward_with_the_short_ring_equals_the_default_form(bf16_mode, n, e, regions, f, t, o):
+    """fused_rows = 2: two workgroups of four waves per CU, a ring of 8 slices each instead of 16 -- the hand-counted vmcnt waits of
+    csrc/fused_rows.hip have a quarter of the slack there (a request is read four steps after it was issued, not twelve).  Same
+    16-row blocks, same arithmetic: every output and gradient identical, run after run."""
+    R = bf16_mode
+    lib = R.load_library()
+    try:
+        p0, h0, g0 = _run(R, n, e, regions, f, t, o, 1, fused_rows=1)
+        for rep in range(3):
+            p1, h1, g1 = _run(R, n, e, regions, f, t, o, 1, seed=0, fused_rows=2)
+            assert torch.equal(p1, p0) and torch.equal(h1, h0), rep
+            for k in g0:
+                assert torch.equal(g1[k], g0[k]), (rep, k)
+    finally:
+        lib.regt_set_option(b"fused_rows", 1)
 
 
 # the fused backward kernel does not depend on F, nor on the forward being the fused one ((333, ..., 32, 7): T F % 64 != 0)
