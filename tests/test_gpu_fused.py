@@ -141,8 +141,9 @@ def test_fused_forward_equals_three_launch_path_bit_for_bit(bf16_mode, n, e, reg
 @pytest.mark.parametrize("n,e,regions,f,t,o", FUSED_SHAPES[:3] + [(1500, 15000, 8, 32, 12, 1), (30000, 250000, 8, 64, 12, 1)])
 def test_row_owning_forward_with_the_short_ring_equals_the_default_form(bf16_mode, n, e, regions, f, t, o):
     """fused_rows = 2: two workgroups of four waves per CU, a ring of 8 slices each instead of 16 -- the hand-counted vmcnt waits of
-    csrc/fused_rows.hip have a quarter of the slack there (a request is read four steps after it was issued, not twelve).  Same
-    16-row blocks, same arithmetic: every output and gradient identical, run after run."""
+    csrc/fused_rows.hip have a quarter of the slack there (a request is read four steps after it was issued, not twelve; this form
+    is what showed that the count reached two slices too far back).  Same 16-row blocks, same arithmetic: every output and gradient
+    identical, run after run -- a wait that is too weak shows up as a difference that comes and goes."""
     R = bf16_mode
     lib = R.load_library()
     try:

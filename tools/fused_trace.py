@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase durations inside the fused kernels (csrc/fused.hip): python tools/fused_trace.py [fwd|bwd]
+"""Phase durations inside the fused kernels (csrc/fused.hip): python tools/fused_trace.py [fwd|bwd|rows] [option=value ...]
 Prints, over all 64-row tiles of one launch, the mean / median shader-clock cycles between the stamps."""
 import ctypes, os, sys
 BWD = len(sys.argv) > 1 and sys.argv[1] == "bwd"
@@ -10,6 +10,9 @@ import numpy as np, torch
 import regtgcn_amd as R
 lib = R.load_library()
 lib.regt_set_gemm_mode(2)
+for kv in sys.argv[2:]:                                         # runtime options, e.g. fused_rows=2
+    name, val = kv.split("=")
+    assert lib.regt_set_option(name.encode(), int(val)) >= 0, kv
 n, e, regions, f, t, o = 40000, 400000, 8, 64, 12, 1
 g = R.data.synthetic_regional_graph(n, e, regions, seed=1)
 dev = torch.device("cuda")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Step time and per-stage device time of one workload under each GEMM arithmetic (0 fp32 MFMA, 1 bf16x3 split, 2 bf16):
-    python tools/mode_bench.py [cfg3|cfg5shard] [modes, e.g. 0,2] [steps]
+    python tools/mode_bench.py [cfg3|cfg5shard] [modes, e.g. 0,2] [steps] [option=value ...]
 cfg5shard = rank 0's share of BASELINE configs[4] (1M nodes / 10M edges / 64 regions / F=64 over 8 GPUs: 125k nodes, 8 of
 the 64 regions, + halo rows filled with random data; no communication)."""
 import ctypes, os, sys, time
@@ -14,6 +14,9 @@ modes = [int(m) for m in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2").split("
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda")
 lib = R.load_library()
+for kv in sys.argv[4:]:                                         # runtime options, e.g. fused_rows=2
+    name, val = kv.split("=")
+    assert lib.regt_set_option(name.encode(), int(val)) >= 0, kv
 T, O = 12, 1
 if wl == "cfg5shard":
     world, F = 8, 64
