@@ -371,4 +371,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
 }
 
+// 4 bf16 (8 bytes) widened to fp32 bit patterns
+__device__ __forceinline__ float4 widen_bf16x4(unsigned lo, unsigned hi) {
+    return make_float4(__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                       __uint_as_float(hi & 0xffff0000u));
+}
+static inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 }  // namespace regt

@@ -345,4 +345,13 @@ int launch_copy_f32(float* dst, const float* src, long n, hipStream_t st);
 int launch_zero_f32(float* dst, long n, hipStream_t st);
 int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st);
 
+// hipFuncSetAttribute is a (slow, host-synchronous) driver call: do it once per kernel, not per launch.
+template <class K>
+static int set_lds_once(K kernel, int bytes, bool* done) {
+    if (*done) return REGT_OK;
+    REGT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    *done = true;
+    return REGT_OK;
+}
+
 }  // namespace regt
