@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.environ.get("REGT_LIB_DIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libregtgcn_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "spmm.hip", "graph.hip", "cell.hip", "gat.hip", "fused.hip", "fused_rows.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "spmm.hip", "graph.hip", "cell.hip", "gat.hip", "fused.hip", "fused_rows.hip", "embed.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "regtgcn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # developer switches, e.g. REGT_HIPCC_FLAGS=-DREGT_WG_TRACE (workgroup phase trace, tools/wg_trace.py)

@@ -231,6 +231,8 @@ bool xbf_ok(const regt_dims& d, const regt_graph& g, bool h_ext, int x_rows, boo
 // the forms stay bit-identical (tests/test_gpu_fused.py).  regt_set_option("fused_rows", 0): the 64-row kernel everywhere; 2: the
 // row-owning kernel as two workgroups of four waves per CU (a test variant, see kernels.h).
 static int g_opt_fused_rows = 1;
+// regt_set_option("embed_kernel", 0): the regional embedding of the fp32 path through the general GEMM core instead of embed.hip (A/B)
+static int g_opt_embed_kernel = 1;
 bool fused_rows_form(const regt_dims& d, const regt_graph& g) {
     return g_opt_fused_rows && fused_forward_rows_ok(d.C, d.F, d.T) && d.regional && !g.overlap && (d.R == 1 || g.region_sorted);
 }
@@ -614,7 +616,13 @@ int forward_impl(const regt_dims& d, const regt_graph& g, const regt_params& p, 
         EpiBiasAct e{L.h, C, bpr, d.regional ? ACT_LRELU : ACT_NONE, d.lrelu_slope};
         e.out_bf16 = abf;
         PROF("gemm_regional", st);
-        TRY(launch_gemm_bias_act(S, M, C, e, st));
+        // fp32 at C = 256, F = 32 with node-sorted region ids: the kernel written for this shape (embed.hip); everything else: the general core
+        if (!wfr && !abf && gemm_mode() == 0 && !fp32_core_wide() && !gemm_desc_table_forced() && g_opt_embed_kernel && d.regional && !g.overlap &&
+            (R == 1 || g.region_sorted) && embed_fp32_ok(M, C, F, T)) {
+            TRY(launch_embed_fp32(Xp, L.LX, A0, Aall, R > 1 ? g.node_region : nullptr, bpr, L.h, M, T, ACT_LRELU, d.lrelu_slope, st));
+        } else {
+            TRY(launch_gemm_bias_act(S, M, C, e, st));
+        }
     }
     // 3. update + reset gates: [Z|R] = sigmoid(h [Uz2;Ur2]^T + (A_hat x) [Gz;Gr]^T + [cz;cr]),  q = h*R
     {
@@ -1225,6 +1233,7 @@ int32_t regt_set_option(const char* name, int32_t value) {
     REGT_CHECK_ARG(name != nullptr, "regt_set_option: name is NULL");
     if (!strcmp(name, "xbf")) { const int prev = xbf_wanted() ? 1 : 0; g_opt_xbf = value ? 1 : 0; return prev; }
     if (!strcmp(name, "fused_rows")) { const int prev = g_opt_fused_rows; g_opt_fused_rows = value == 2 ? 2 : (value ? 1 : 0); return prev; }
+    if (!strcmp(name, "embed_kernel")) { const int prev = g_opt_embed_kernel; g_opt_embed_kernel = value ? 1 : 0; return prev; }
     if (!strcmp(name, "fused_bwd")) { const int prev = fused_bwd_wanted() ? 1 : 0; g_opt_fused_bwd = value ? 1 : 0; return prev; }
     if (!strcmp(name, "spmm_rows")) return spmm_rows_option(value);
     if (!strcmp(name, "dgrad1_gen")) return dgrad1_gen_option(value);

@@ -345,6 +345,11 @@ int launch_copy_f32(float* dst, const float* src, long n, hipStream_t st);
 int launch_zero_f32(float* dst, long n, hipStream_t st);
 int launch_mse_grad(const float* pred, const float* y, float* dpred, float* loss_out, long n, float scale, hipStream_t st);
 
+// the regional embedding of the fp32 path at C = 256, F = 32 as a kernel of its own (embed.hip); region ids must ascend with the node number
+bool embed_fp32_ok(long M, int C, int F, int T);
+int launch_embed_fp32(const float* X, const float* LX, const float* A0, const float* Aall, const int* node_region, const float* bias,
+                      float* out, long M, int T, int act, float slope, hipStream_t st);
+
 // hipFuncSetAttribute is a (slow, host-synchronous) driver call: do it once per kernel, not per launch.
 template <class K>
 static int set_lds_once(K kernel, int bytes, bool* done) {

@@ -58,7 +58,7 @@ def test_every_runtime_option_is_known_and_restores():
     sys.path.insert(0, ROOT)
     import regtgcn_amd as R
     lib = R.load_library()
-    defaults = {b"xbf": 1, b"fused_bwd": 1, b"fused_rows": 1, b"spmm_rows": 0, b"dgrad1_gen": 1, b"wgrad_ring": 6, b"wgrad_tile": 256,
+    defaults = {b"xbf": 1, b"fused_bwd": 1, b"fused_rows": 1, b"embed_kernel": 1, b"spmm_rows": 0, b"dgrad1_gen": 1, b"wgrad_ring": 6, b"wgrad_tile": 256,
                 b"wgrad_ring256": 2, b"wgrad_bnw64": 1, b"wgrad_wave": 1, b"wgrad_pairs": 2, b"tgcn_collapse": 1}
     for name, dflt in defaults.items():
         prev = lib.regt_set_option(name, dflt)
