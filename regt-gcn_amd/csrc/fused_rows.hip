@@ -19,10 +19,14 @@
 // element while T <= 16 (a node then meets at most two blocks); the three-launch path sums the same blocks (`node_sum_rows` of
 // CandArgs), so outputs stay bit-identical to it (tests/test_gpu_fused.py).  Longer periods, C != 256 or region ids that are not
 // sorted by node keep fused_fwd_kernel.
-// Tried on this schedule and dropped (profiles/r05_fused_rows_offset_form.txt): waves 4-7 running four barrier-to-barrier steps
-// behind waves 0-3, so that every SIMD has one wave in a K loop and one in an epilogue (1.91 vs 1.69 ms: a step costs ~1000 cycles
-// either way -- barrier + LDS-DMA issue, not MFMA -- and the candidate rounds of the two groups then run one after the other);
-// transposing the whole accumulator block through the image before the epilogue rounds (1.72 vs 1.63 ms).
+// Tried on this schedule and dropped, all bit-identical (profiles/r05_fused_rows_offset_form.txt): waves 4-7 running four
+// barrier-to-barrier steps behind waves 0-3, so that every SIMD has one wave in a K loop and one in an epilogue (1.91 vs 1.69 ms: a
+// step costs ~1000 cycles either way -- barrier + LDS-DMA issue, not MFMA -- and the candidate rounds of the two groups then run one
+// after the other); the whole accumulator block transposed through the image before the epilogue rounds (1.72 vs 1.63); the next
+// tile's rows and the region ids loaded in inline asm with hand-placed waits, so that hipcc's own vmcnt(k) in front of their first
+// use does not wait for the ring's requests (1.667 vs 1.630: what those waits drain has landed by then anyway); per-node sums by a
+// DPP scan in the epilogue layout or with one store + one atomic per round (1.85 / 1.68-1.87 vs 1.65: the epilogues are bound by
+// instruction issue).
 #include <type_traits>
 
 #include "fused_common.h"
@@ -48,7 +52,7 @@ struct FusedRowsLds {
     static constexpr int IMG_OFF = BIAS_OFF + 4 * FR_C * 4;
     static constexpr int RING_OFF = IMG_OFF + NW * FR_IMG_B;
     static constexpr int NEXT_OFF = RING_OFF + SLOTS * FR_SLICE_B;   // the workgroup's next tile (drawn from the tile counter)
-    static constexpr int BYTES = NEXT_OFF + 16;                  // (two words, used alternately)
+    static constexpr int BYTES = NEXT_OFF + 16;
 };
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -61,18 +65,6 @@ typedef __attribute__((address_space(3))) void fr_lds_void;
 __device__ __forceinline__ constexpr int fr_par(int r) { return ((r >> 1) & 3) | (r & 4); }
 
 }  // namespace
-
-// compile-time loops and indices: slice numbers and wait counts are constant expressions at every site (the waits are immediates)
-template <int N> using fr_ic = std::integral_constant<int, N>;
-template <int I, int N, class Fn>
-__device__ __forceinline__ void fr_for(Fn&& f) {
-    if constexpr (I < N) { f(fr_ic<I>{}); fr_for<I + 1, N>(f); }
-}
-template <int N>
-__device__ __forceinline__ void fr_wait_vm() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 
 // what the ring's producer and the tile loop need to know about a tile: its first region and the number of regions it touches
 // (region ids sorted by node: a tile's regions are a range)
@@ -94,7 +86,6 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
     const long tiles = (a.M + FR_ROWS - 1) / FR_ROWS;
     const unsigned ring_lds = (unsigned)(size_t)(fr_lds_void*)(flds + L::RING_OFF);      // LDS byte address of the ring
     float* imgw = reinterpret_cast<float*>(flds + L::IMG_OFF + v * FR_IMG_B);
-    unsigned* nextw = reinterpret_cast<unsigned*>(flds + L::NEXT_OFF);
 // developer trace (REGT_FUSED_TRACE=1, tools/fused_trace.py rows): stamps of thread 0 -- 0 tile start; per unit u (embedding j=0,1; R j=0,1;
     // Z0, cand0, Z1, cand1): 1 + 2 u after its K loop, 2 + 2 u after its epilogue
 #define FT_MARK(i) do { if (a.trace && tid == 0) a.trace[(long)FT_TRACE_SLOTS * tile + (i)] = (long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -103,13 +94,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
         FrTileInfo t{0, 1};
         if (a.node_region && tile < tiles) {
             const long m0 = tile * FR_ROWS, m1 = (m0 + FR_ROWS < a.M ? m0 + FR_ROWS : a.M) - 1;
-            // (the quotients come out of the vector ALU: made scalar again, and the region ids read with scalar loads -- the wait
-            // for a vector load here is vmcnt(0), which drains the ring)
-            const unsigned n0 = __builtin_amdgcn_readfirstlane((unsigned)m0 / uT), n1 = __builtin_amdgcn_readfirstlane((unsigned)m1 / uT);
-            int r0, r1;                                          // (inline asm: hipcc reads this array with vector loads even at a scalar address)
-            asm volatile("s_nop 4\n\ts_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r0), "=&s"(r1) : "s"(a.node_region + n0), "s"(a.node_region + n1) : "memory");
-            t.rg_first = r0;
-            t.nreg = r1 - r0 + 1;
+            t.rg_first = a.node_region[(unsigned)m0 / uT];
+            t.nreg = a.node_region[(unsigned)m1 / uT] - t.rg_first + 1;
         }
         return t;
     };
@@ -146,12 +132,13 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
             mo = w == 0 ? a.o_uz : (w == 1 ? a.o_gzr : (w == 2 ? a.o_uh : a.o_gh));
             nb = 4 * j; k16 = (w & 1) ? F / 16 : C / 16;
         }
-        // (readfirstlane: no-ops on values that are uniform anyway -- the slot counter is updated under wave-uniform branches, which
-        // hipcc's divergence analysis does not always see through)
-        const char* src = a.wbase + __builtin_amdgcn_readfirstlane(mo + (k16 == C / 16 ? voff_c : voff_f) + (unsigned)((nb * k16 + 2 * kb) * 1024));
-        const unsigned m0v = __builtin_amdgcn_readfirstlane(ring_lds + p_slot * FR_SLICE_B + v * 1024);
+        const char* src = a.wbase + (mo + (k16 == C / 16 ? voff_c : voff_f) + (unsigned)((nb * k16 + 2 * kb) * 1024));
+        const unsigned m0v = ring_lds + p_slot * FR_SLICE_B + v * 1024;
         // (inline asm: hipcc drains the builtin form -- vmcnt(0) in front of every LDS read; the waits for these requests are
-        // written by hand in `consume`.  M0 = LDS base of the wave's 1 KB, lane l lands at + 16 l)
+        // written by hand in `consume`.  M0 = LDS base of the wave's 1 KB, lane l lands at + 16 l.  s_nop 3: the source pointer may
+        // have been restored from a VGPR lane (v_readlane) by the instruction before the asm statement, and a vector-memory
+        // instruction needs five wait states behind a VALU write of an SGPR it reads -- hipcc pads its own instructions, not the
+        // inside of an asm statement; an experimental build with asm row loads faulted at address 0 on exactly that.  Free in an A/B)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0v), "v"(dma_voff), "s"(src) : "memory");
         if (RPW == 2) {
             const char* src2 = src + 2 * k16 * 1024;
@@ -236,8 +223,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
 #endif
         }
     };
-    auto consume = [&](auto sc, f32x4 (&acc)[8], const bf16x8& af) {
-        constexpr int s = decltype(sc)::value;                   // (the slice number is a constant expression at every call site)
+    auto consume = [&](int s, f32x4 (&acc)[8], const bf16x8& af) {
         // One barrier per TWO slices (even s; 16 MFMAs per wave in between -- with one per slice the K loops ran at ~500 cycles per
         // slice for 256 of matrix work): slices s + 1 and s + 2 have landed -- this wave's own requests for them are done when all of
         // its vector-memory operations are, except the ones issued after them (they retire in issue order): the requests s + 3 ..
@@ -326,13 +312,6 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
     //      (r, g): k = 32 kb + 8 g .. + 7 of row r), the region and the attention probability of the lane's row
     bf16x8 xf[KF], lf[KF], axf[KF];
     int rg_row; float pt_row;
-    // (s_nop 4 in front of every load written in asm: an SGPR operand may have been restored from a VGPR lane (v_readlane) by the
-    // instruction before, and a vector-memory instruction that reads an SGPR needs five wait states behind a VALU write of it --
-    // hipcc pads its own instructions, not the inside of an asm statement.  The F = 32 kernel faulted at address 0 on exactly that.)
-    // (inline asm loads: hipcc does not see the ring's requests, so the waits it puts in front of the first use of a load of its own
-    // -- vmcnt(number of ITS later operations) -- drained the ring at every tile start.  These loads are waited for by hand,
-    // `rows_landed`, before the end of the tile that issued them; the empty asm there makes the registers defined from hipcc's
-    // point of view only after the wait)
     auto request_rows = [&](long tile) {
         const long m0 = tile * FR_ROWS + 16 * v;                 // (past the last tile / row: zero records, loads return 0)
         const long left = a.M - m0;
@@ -343,42 +322,29 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
         const int afo = r * F * 2 + g * 16;
 #pragma unroll
         for (int kb = 0; kb < KF; ++kb) {
-            const int so = kb * 64;
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(xf[kb]) : "v"(afo), "s"(sX), "s"(so) : "memory");
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lf[kb]) : "v"(afo), "s"(sLX), "s"(so) : "memory");
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(axf[kb]) : "v"(afo), "s"(sAX), "s"(so) : "memory");
+            xf[kb] = f_ldfrag(sX, afo, kb * 64);
+            lf[kb] = f_ldfrag(sLX, afo, kb * 64);
+            axf[kb] = f_ldfrag(sAX, afo, kb * 64);
         }
         const unsigned m = (unsigned)m0 + (unsigned)r, nd = m / uT;
-        const bool ok = r < nv;                                  // (rows past the end: their L~ x loads returned zeros, whatever the region says)
-        const unsigned po = ok ? 4u * (m - nd * uT) : 0u, ro = ok ? 4u * nd : 0u;
-        asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(pt_row) : "v"(po), "s"(a.probs) : "memory");
-        rg_row = 0;
-        if (a.node_region) asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(rg_row) : "v"(ro), "s"(a.node_region) : "memory");
-    };
-    // (to be called behind fr_wait_vm<n>(), n = vector-memory operations issued after request_rows -- fewer is safe; not a generic
-    // lambda: clang rejects asm operands that name captured variables inside one)
-    auto rows_landed = [&]() {
-#pragma unroll
-        for (int kb = 0; kb < KF; ++kb) asm volatile("" : "+v"(xf[kb]), "+v"(lf[kb]), "+v"(axf[kb]));
-        asm volatile("" : "+v"(pt_row), "+v"(rg_row));
+        const bool ok = r < nv;
+        rg_row = ok ? (a.node_region ? a.node_region[nd] : 0) : -1;
+        pt_row = a.probs[ok ? m - nd * uT : 0];
     };
     long tile = blockIdx.x;
     FrTileInfo info = tile_info(tile);
     request_rows(tile);
-    fr_wait_vm<0>();
-    rows_landed();
-    int tpar = 0;
 #pragma unroll
-        for (int s = 0; s < FR_AHEAD - 1; ++s) request(s, info.rg_first);
-        // (the first tile's first wait counts operations that a steady-state tile has behind its requests -- here they are in front:
-        // make sure slices 0, 1 and 2 have landed before the loop)
-        wait_landed(RPW * (FR_AHEAD - 4));
+    for (int s = 0; s < FR_AHEAD - 1; ++s) request(s, info.rg_first);
+    // (the first tile's first wait counts operations that a steady-state tile has behind its requests -- here they are in front:
+    // make sure slices 0, 1 and 2 have landed before the loop)
+    wait_landed(RPW * (FR_AHEAD - 4));
 
 #pragma unroll 1
     while (tile < tiles) {
         // (the next tile is drawn from a counter in the workspace, not blockIdx + k gridDim: workgroups that start late -- a kernel of
         // the side stream holding their CU -- must not find a whole stride of tiles waiting for them; read behind the ring's barriers)
-        if (tid == 0) nextw[tpar] = a.tile_ctr ? atomicAdd(a.tile_ctr, 1u) + gridDim.x : (unsigned)(tile + gridDim.x);
+        if (tid == 0) *reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF) = a.tile_ctr ? atomicAdd(a.tile_ctr, 1u) + gridDim.x : (unsigned)(tile + gridDim.x);
         const long m0 = tile * FR_ROWS + 16 * v;                 // the wave's first row
         const long left = a.M - m0;
         const int nv = (int)(left < 0 ? 0 : (left < 16 ? left : 16));      // its valid rows
@@ -413,10 +379,12 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
             f32x4 acc[8];
             zero8(acc);
             const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-            fr_for<0, KF>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<2 * KF * j + kb>{}, acc, xf[kb]); });
+#pragma unroll
+            for (int kb = 0; kb < KF; ++kb) consume(2 * KF * j + kb, acc, xf[kb]);
             {                                                    // the tile's first region: rows of other regions contribute zeros
                 const bool mine = rgl == rg_cur;
-                fr_for<0, KF>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<2 * KF * j + KF + kb>{}, acc, mine ? lf[kb] : zero); });
+#pragma unroll
+                for (int kb = 0; kb < KF; ++kb) consume(2 * KF * j + KF + kb, acc, mine ? lf[kb] : zero);
             }
 #pragma unroll 1
             for (int p = 1; p < nreg; ++p) {                     // further regions of the tile (rare): their weights straight from L2
@@ -436,8 +404,8 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
             FT_MARK(1 + 2 * j);
             const EpiGeo eg = epi_geo();
             const float ns = a.act_lrelu ? a.slope : 1.0f;
-            fr_for<0, 4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_barrier(0);      // (one round at a time: interleaved rounds cost registers, then spills whose reloads drain vmcnt)
                 stage(eg, acc[2 * q], acc[2 * q + 1]);
                 const V8 vv = img8(eg);
@@ -448,12 +416,12 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
                 const u32x4_t pk = f_pack8(o);
                 __builtin_amdgcn_raw_buffer_store_b128(pk, sh, eg.ro + (128 * j + 32 * q) * 2, 0, 0);
                 hA[4 * j + q] = __builtin_bit_cast(bf16x8, pk);
-            });
+            }
             FT_MARK(2 + 2 * j);
         };
         unit_embed(std::integral_constant<int, 0>{});
         unit_embed(std::integral_constant<int, 1>{});
-        const long tnext = __builtin_amdgcn_readfirstlane(nextw[tpar]);     // (written >= 8 barriers ago; the barriers' asm statements clobber memory)
+        const long tnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(flds + L::NEXT_OFF));
         const FrTileInfo info_next = tile_info(tnext);           // (first used by the requests that reach into the next tile: the last FR_AHEAD slices)
         rg_nxt = info_next.rg_first; has_next = tnext < tiles;
         // ---- reset gate R = sigmoid(h Ur^T + (A_hat x) Gr^T + cr), q = h R: the candidate's A operand --------------------------------
@@ -462,12 +430,14 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
             constexpr int j = decltype(jc)::value;
             f32x4 acc[8];
             zero8(acc);
-            fr_for<0, 8>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * j + kb>{}, acc, hA[kb]); });
-            fr_for<0, KF>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * j + 8 + kb>{}, acc, axA[kb]); });
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) consume(4 * KF + (8 + KF) * j + kb, acc, hA[kb]);
+#pragma unroll
+            for (int kb = 0; kb < KF; ++kb) consume(4 * KF + (8 + KF) * j + 8 + kb, acc, axA[kb]);
             FT_MARK(5 + 2 * j);
             const EpiGeo eg = epi_geo();
-            fr_for<0, 4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage(eg, acc[2 * q], acc[2 * q + 1]);
                 const V8 vv = img8(eg);
@@ -481,7 +451,7 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
                 const u32x4_t pq = f_pack8(qv);
                 __builtin_amdgcn_raw_buffer_store_b128(pq, sq, eg.ro + (128 * j + 32 * q) * 2, 0, 0);
                 qA[4 * j + q] = __builtin_bit_cast(bf16x8, pq);
-            });
+            }
             FT_MARK(6 + 2 * j);
         };
         unit_r(std::integral_constant<int, 0>{});
@@ -494,32 +464,36 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
             {
                 f32x4 acc[8];
                 zero8(acc);
-                fr_for<0, 8>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * (2 + 2 * j) + kb>{}, acc, hA[kb]); });
-                fr_for<0, KF>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * (2 + 2 * j) + 8 + kb>{}, acc, axA[kb]); });
+#pragma unroll
+                for (int kb = 0; kb < 8; ++kb) consume(4 * KF + (8 + KF) * (2 + 2 * j) + kb, acc, hA[kb]);
+#pragma unroll
+                for (int kb = 0; kb < KF; ++kb) consume(4 * KF + (8 + KF) * (2 + 2 * j) + 8 + kb, acc, axA[kb]);
                 FT_MARK(9 + 4 * j);
                 const EpiGeo eg = epi_geo();
-                fr_for<0, 4>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
                     __builtin_amdgcn_sched_barrier(0);
                     stage(eg, acc[2 * q], acc[2 * q + 1]);
-                const V8 vv = img8(eg);
+                    const V8 vv = img8(eg);
                     const V8 b = bias8(C + 128 * j + 32 * q + 8 * g);
                     zk[q] = f_pack8(f_sigmoid8(vv, b));
                     __builtin_amdgcn_raw_buffer_store_b128(zk[q], sZR, eg.rzo + (128 * j + 32 * q) * 2, 0, 0);
-                });
+                }
             }
             FT_MARK(10 + 4 * j);
             f32x4 acc[8];
             zero8(acc);
-            fr_for<0, 8>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * (3 + 2 * j) + kb>{}, acc, qA[kb]); });
-            fr_for<0, KF>([&](auto kc) { constexpr int kb = decltype(kc)::value; consume(fr_ic<4 * KF + (8 + KF) * (3 + 2 * j) + 8 + kb>{}, acc, axA[kb]); });
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) consume(4 * KF + (8 + KF) * (3 + 2 * j) + kb, acc, qA[kb]);
+#pragma unroll
+            for (int kb = 0; kb < KF; ++kb) consume(4 * KF + (8 + KF) * (3 + 2 * j) + 8 + kb, acc, axA[kb]);
             FT_MARK(11 + 4 * j);
             const EpiGeo eg = epi_geo();
             if (j == 1) { info = info_next; request_rows(tnext); }   // the next tile's rows, before this tile's last stores
             const long ohcol = (long)node0 * C + 128 * j;
             const __amdgpu_buffer_rsrc_t sOH = f_rsrc(a.OH + ohcol, (a.nodes * C - ohcol) * 4);
-            fr_for<0, 4>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage(eg, acc[2 * q], acc[2 * q + 1]);
                 const V8 vv = img8(eg);
@@ -534,9 +508,6 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bl.v[i] = __fmul_rn(pt, gru_blend(Zv.v[i], hv.v[i], ht.v[i]));
                 __builtin_amdgcn_raw_buffer_store_b128(f_pack8(ht), sHt, eg.ro + (128 * j + 32 * q) * 2, 0, 0);
-#if defined(REGT_FUSED_ABL) && (REGT_FUSED_ABL & 8)      // timing-only developer build: no per-node sums
-                asm volatile("" :: "v"(bl.v[0]), "v"(bl.v[1]), "v"(bl.v[2]), "v"(bl.v[3]), "v"(bl.v[4]), "v"(bl.v[5]), "v"(bl.v[6]), "v"(bl.v[7]));
-#else
                 *reinterpret_cast<float4*>(imgw + eg.e_lo) = make_float4(bl.v[0], bl.v[1], bl.v[2], bl.v[3]);
                 *reinterpret_cast<float4*>(imgw + eg.e_hi) = make_float4(bl.v[4], bl.v[5], bl.v[6], bl.v[7]);
                 // Per-node sums over the wave's 16 rows, in row order (see fused.hip: one running sum per lane = column lr of the
@@ -565,19 +536,13 @@ __global__ __launch_bounds__(64 * NW, 2) void fused_fwd_rows_kernel(FusedFwdArgs
                         }
                     }
                 }
-#endif
-            });
+            }
             FT_MARK(12 + 4 * j);
         };
         unit_zc(std::integral_constant<int, 0>{});
         unit_zc(std::integral_constant<int, 1>{});
-        // the next tile's rows: behind them the rounds of the last epilogue stored once each (+ per-node sums, not counted; one
-        // round less is counted in the offset form) and, in the offset form, group A requested three pairs
-        fr_wait_vm<4>();
-        rows_landed();
         first_tile = false;
         tile = tnext;
-        tpar ^= 1;
     }
     // (the ring holds no request any more: the producer stopped with the last tile's last slice, which has been consumed)
 #undef FT_MARK
