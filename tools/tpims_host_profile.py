@@ -28,13 +28,18 @@ for i in range(30):
     step(i)
 torch.cuda.synchronize()
 K = 300
-t0 = time.perf_counter()
-for i in range(K):
-    step(i)
-t_host = time.perf_counter() - t0
-torch.cuda.synchronize()
-t_all = time.perf_counter() - t0
-print(f"host enqueue {1e3 * t_host / K:.3f} ms/step, wall {1e3 * t_all / K:.3f} ms/step")
+def timed(label):
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    print(f"{label}: host enqueue {1e3 * t_host / K:.3f} ms/step, wall {1e3 * t_all / K:.3f} ms/step")
+timed("autograd engine threads (default)")
+with torch.autograd.set_multithreading_enabled(False):      # backward on the calling thread: no hand-over to the device's engine thread
+    timed("backward on the calling thread")
+timed("autograd engine threads (default)")
 pr = cProfile.Profile()
 pr.enable()
 for i in range(K):
