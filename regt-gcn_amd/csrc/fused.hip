@@ -794,7 +794,8 @@ __global__ __launch_bounds__(256, 2) void fused_bwd_kernel(FusedBwdArgs a) {
             *reinterpret_cast<u32x4_t*>(Rp + plane_off(row, c)) = pr;
             __builtin_amdgcn_raw_buffer_store_b128(pr, sdzr, (row * 2 * C + C + c) * 2, 0, 0);
             {
-                const u32x4_t pk = f_pack8(dh);
+                u32x4_t pk = f_pack8(dh);
+                asm volatile("" : "+v"(pk));                     // (pinned: hipcc otherwise sinks this arithmetic to its use in phase D)
                 if (j == 0) dhk[0][rnd] = pk;
                 else dhk[1][rnd] = pk;
             }
