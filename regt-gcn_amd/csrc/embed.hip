@@ -161,13 +161,17 @@ __global__ __launch_bounds__(512, 2) void embed_fp32_kernel(EmbedArgs a) {
                     for (int cb = 0; cb < 4; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[s][cb], b, acc[cb], 0, 0, 0);
                 }
                 const int row = 64 * rh + 16 * rb + c - lo;      // relative to the pass's first row: negative = before it (dropped: huge offset)
-                const int voff = row * (EM_C * 4) + (64 * cq + 4 * g) * 4;
+                const int voff = row < 0 ? 0x7ffffff0 : row * (EM_C * 4) + (64 * cq + 4 * g) * 4;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     f32x4 v = acc[cb];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * a.ns;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), so, row < 0 ? 0x7ffffff0 : voff, 64 * cb, 0);
+                    // (the column block's offset goes into the vector offset -- an immediate for the instruction -- not into soffset: a
+                    // 16-byte buffer store with an SGPR soffset whose data registers the next instruction overwrites picks up the NEW
+                    // value now and then on gfx950, and hipcc pads that hazard only when soffset is an immediate (gemm.hip, top).  With
+                    // the row-block loop unrolled the next MFMA's destination WAS the store's data: wrong rows in half of the runs)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), so, voff + 64 * cb, 0, 0);
                 }
             }
         }
