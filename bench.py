@@ -415,6 +415,8 @@ def stage_kernel(stage, mode):
         return ["cell_bwd8_kernel", "cell_bwd_kernel"] if mode == 2 else ["cell_bwd_kernel"]
     if stage == "spmm":
         return ["spmm_dual_panel_bf16_kernel", "spmm_dual_panel_kernel"] if mode == 2 else ["spmm_dual_panel_kernel"]
+    if stage == "gemm_regional":
+        return ["embed_fp32_kernel", "gemm_flat_split_kernel<regt::EpiBiasActF, true"]
     return None
 
 
